@@ -1,0 +1,398 @@
+/*
+ * oracle/mdec_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar CPU restatement of the reference's MDEC "BS" frame encoder
+ * (psxavenc/mdec.c:256-319 LUT construction, :321-385 bit writer, :438-510 block coder,
+ * :580-755 encode_frame_bs, :757-836 encode_sector_str).  It exists so the HIP path in
+ * psxavenc_amd/csrc can be diffed against something that follows the reference's
+ * algorithm step by step; nothing under psxavenc_amd/ may include, link or call it
+ * (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do).
+ *
+ * PARITY UNPINNED at the 8x8 forward DCT: the reference calls FFmpeg's
+ * AVDCT.fdct (mdec.c:640; libavcodec is an un-vendored dependency, version 8.0.1 in the
+ * release CI, .github/scripts/build.sh:4, configured --disable-mmx, build.sh:36-56).
+ * libavcodec is absent from /root/reference and from this image, so psxavenc/mdec.c
+ * cannot be compiled here without writing a stand-in for <libavcodec/avdct.h>, which
+ * the build rules forbid.  orc_fdct_islow8() below restates the published algorithm
+ * that configuration selects -- the IJG "jfdctint" slow-but-accurate integer DCT
+ * (Loeffler/Ligtenberg/Moschytz, 13-bit constants, 4 extra bits kept after the row
+ * pass), as specialised for 8-bit samples in libavcodec/jfdctint_template.c
+ * (ff_jpeg_fdct_islow_8).  Everything downstream of the DCT follows mdec.c directly.
+ *
+ * Built WITHOUT -ffast-math on purpose: DIVIDE_ROUNDED (mdec.c:438) is
+ * round-half-away-from-zero of an exactly representable quotient neighbourhood, which
+ * IEEE division + round() gives bit-for-bit ("rounding division").
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bs_vlc_tables.h"
+#include "mdec_oracle.h"
+
+/* ------------------------------------------------------------------------------------
+ * 8x8 forward DCT, jfdctint "islow" for 8-bit samples (see header comment).
+ * One generic 1-D butterfly; the two passes differ only in their output scaling:
+ *   rows:    even outputs << 4,             odd/rotated outputs descaled by 13-4
+ *   columns: even outputs descaled by 4,    odd/rotated outputs descaled by 13+4
+ * and every result is stored back as int16 between and after the passes.
+ * ---------------------------------------------------------------------------------- */
+enum {
+	C_0_298631336 = 2446,  C_0_390180644 = 3196,  C_0_541196100 = 4433,
+	C_0_765366865 = 6270,  C_0_899976223 = 7373,  C_1_175875602 = 9633,
+	C_1_501321110 = 12299, C_1_847759065 = 15137, C_1_961570560 = 16069,
+	C_2_053119869 = 16819, C_2_562915447 = 20995, C_3_072711026 = 25172
+};
+
+static inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+static void fdct_1d(int16_t *p, int stride, int column_pass) {
+	const int32_t d0 = p[0 * stride], d1 = p[1 * stride], d2 = p[2 * stride], d3 = p[3 * stride];
+	const int32_t d4 = p[4 * stride], d5 = p[5 * stride], d6 = p[6 * stride], d7 = p[7 * stride];
+
+	/* even half */
+	const int32_t s07 = d0 + d7, s16 = d1 + d6, s25 = d2 + d5, s34 = d3 + d4;
+	const int32_t e0 = s07 + s34, e3 = s07 - s34, e1 = s16 + s25, e2 = s16 - s25;
+	/* odd half */
+	int32_t o0 = d3 - d4, o1 = d2 - d5, o2 = d1 - d6, o3 = d0 - d7;
+
+	const int rot_shift = column_pass ? 13 + 4 : 13 - 4;
+
+	if (column_pass) {
+		p[0 * stride] = (int16_t)descale(e0 + e1, 4);
+		p[4 * stride] = (int16_t)descale(e0 - e1, 4);
+	} else {
+		p[0 * stride] = (int16_t)((e0 + e1) * 16);
+		p[4 * stride] = (int16_t)((e0 - e1) * 16);
+	}
+	const int32_t r = (e2 + e3) * C_0_541196100;
+	p[2 * stride] = (int16_t)descale(r + e3 * C_0_765366865, rot_shift);
+	p[6 * stride] = (int16_t)descale(r - e2 * C_1_847759065, rot_shift);
+
+	int32_t z1 = o0 + o3, z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+	const int32_t z5 = (z3 + z4) * C_1_175875602;
+	o0 *= C_0_298631336;
+	o1 *= C_2_053119869;
+	o2 *= C_3_072711026;
+	o3 *= C_1_501321110;
+	z1 *= -C_0_899976223;
+	z2 *= -C_2_562915447;
+	z3 = z3 * -C_1_961570560 + z5;
+	z4 = z4 * -C_0_390180644 + z5;
+	p[7 * stride] = (int16_t)descale(o0 + z1 + z3, rot_shift);
+	p[5 * stride] = (int16_t)descale(o1 + z2 + z4, rot_shift);
+	p[3 * stride] = (int16_t)descale(o2 + z2 + z3, rot_shift);
+	p[1 * stride] = (int16_t)descale(o3 + z1 + z4, rot_shift);
+}
+
+void orc_fdct_islow8(int16_t *blk) {
+	for (int r = 0; r < 8; r++) fdct_1d(blk + 8 * r, 1, 0);
+	for (int c = 0; c < 8; c++) fdct_1d(blk + c, 8, 1);
+}
+
+/* ------------------------------------------------------------------------------------
+ * VLC maps, same shape as the reference's: (bits << 24) | value, AC indexed by
+ * (run << 10) | (level & 0x3FF), DC by (component << 9) | (delta & 0x1FF).
+ * mdec.c:254-319.
+ * ---------------------------------------------------------------------------------- */
+#define PACK(bits, value) (((uint32_t)(bits) << 24) | (uint32_t)(value))
+
+static uint32_t bitstring(const char *s, int *len) {
+	uint32_t v = 0;
+	int n = 0;
+	for (; s[n]; n++) v = (v << 1) | (uint32_t)(s[n] - '0');
+	*len = n;
+	return v;
+}
+
+struct orc_mdec_luts {
+	uint32_t ac[0x10000];
+	uint32_t dc[3 * 0x200];
+	uint8_t dc_valid[3 * 0x200];
+};
+
+static void fill_dc(struct orc_mdec_luts *L, int comp, const char *zero, const char *const prefix[8]) {
+	int plen;
+	uint32_t pv = bitstring(zero, &plen);
+	L->dc[(comp << 9) | 0] = PACK(plen, pv);
+	L->dc_valid[(comp << 9) | 0] = 1;
+	for (int m = 0; m < 8; m++) { /* m = magnitude bits - 1 */
+		pv = bitstring(prefix[m], &plen);
+		const int total = plen + 1 + m;
+		for (int j = 0; j < (1 << m); j++) {
+			const int pos = (j + (1 << m)) & 0x1FF;           /* +2^m .. +2^(m+1)-1 */
+			const int neg = (j - ((2 << m) - 1)) & 0x1FF;     /* -(2^(m+1)-1) .. -2^m */
+			L->dc[(comp << 9) | pos] = PACK(total, (pv << (m + 1)) | (1u << m) | (uint32_t)j);
+			L->dc[(comp << 9) | neg] = PACK(total, (pv << (m + 1)) | (uint32_t)j);
+			L->dc_valid[(comp << 9) | pos] = 1;
+			L->dc_valid[(comp << 9) | neg] = 1;
+		}
+	}
+}
+
+static struct orc_mdec_luts *g_luts;
+
+static const struct orc_mdec_luts *luts(void) {
+	if (g_luts) return g_luts;
+	struct orc_mdec_luts *L = calloc(1, sizeof(*L));
+	for (uint32_t i = 0; i <= 0xFFFF; i++) L->ac[i] = PACK(22, (1u << 16) | i);   /* escape */
+	for (int i = 0; i < ORC_AC_CODE_COUNT; i++) {
+		int n;
+		const uint32_t v = bitstring(orc_ac_codes[i].bits, &n);
+		const int run = orc_ac_codes[i].run, lvl = orc_ac_codes[i].level;
+		L->ac[(run << 10) | ((+lvl) & 0x3FF)] = PACK(n + 1, (v << 1) | 0);
+		L->ac[(run << 10) | ((-lvl) & 0x3FF)] = PACK(n + 1, (v << 1) | 1);
+	}
+	fill_dc(L, 0, ORC_DC_CHROMA_ZERO, orc_dc_chroma_prefix);   /* Cr */
+	fill_dc(L, 1, ORC_DC_CHROMA_ZERO, orc_dc_chroma_prefix);   /* Cb */
+	fill_dc(L, 2, ORC_DC_LUMA_ZERO, orc_dc_luma_prefix);       /* Y  */
+	g_luts = L;
+	return L;
+}
+
+uint32_t orc_mdec_ac_code(int run, int level) { return luts()->ac[((run & 63) << 10) | (level & 0x3FF)]; }
+uint32_t orc_mdec_dc_code(int comp, int delta) { return luts()->dc[(comp << 9) | (delta & 0x1FF)]; }
+
+/* ------------------------------------------------------------------------------------
+ * Bit writer: MSB-first into 16-bit words, each word stored low byte first, starting at
+ * byte 8.  The capacity test sits between the two byte stores of a word exactly as in
+ * mdec.c:321-333 (so an odd budget loses its last byte); unlike the reference the store
+ * that would land one byte past the buffer on a rejected attempt is skipped.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	uint8_t *out;
+	int cap, used;
+	uint16_t acc;
+	int room;
+} bitsink_t;
+
+static int sink_flush(bitsink_t *s) {
+	if (s->room < 16) {
+		if (s->used < s->cap) s->out[s->used] = (uint8_t)s->acc;
+		s->used++;
+		if (s->used >= s->cap) return 0;
+		s->out[s->used++] = (uint8_t)(s->acc >> 8);
+	}
+	s->room = 16;
+	s->acc = 0;
+	return 1;
+}
+
+static int sink_put(bitsink_t *s, int n, uint32_t v) {
+	while (n > 0) {
+		if (s->room == 0 && !sink_flush(s)) return 0;
+		const int take = n < s->room ? n : s->room;
+		const uint32_t chunk = (v >> (n - take)) & ((1u << take) - 1u);
+		s->acc |= (uint16_t)(chunk << (s->room - take));
+		s->room -= take;
+		n -= take;
+	}
+	return 1;
+}
+
+/* mdec.c:438 -- round half away from zero of n/d, computed in double like the reference */
+static inline int div_rounded(int n, int d) { return (int)round((double)n / (double)d); }
+
+/* mdec.c:260-267 -- AC/DC level range; 0x1FF is kept free for the v2 end-of-frame code */
+static inline int clamp_level(int v) {
+	v = (int16_t)v;
+	return v < -0x200 ? -0x200 : (v > 0x1FE ? 0x1FE : v);
+}
+
+typedef struct {
+	int codec;
+	int block_type;
+	int16_t last_dc[3];
+	int hwords;
+} blockcoder_t;
+
+/* mdec.c:441-510 */
+static int code_block(bitsink_t *s, blockcoder_t *bc, const struct orc_mdec_luts *L,
+                      const int16_t *blk, const int16_t *qt) {
+	int dc = clamp_level(div_rounded(blk[0], qt[0]));
+
+	if (bc->codec == ORC_BS_V2) {
+		if (!sink_put(s, 10, (uint32_t)dc & 0x3FF)) return 0;
+	} else {
+		const int comp = bc->block_type < 2 ? bc->block_type : 2;
+		int delta = div_rounded(dc - bc->last_dc[comp], 4);
+		bc->last_dc[comp] = (int16_t)(bc->last_dc[comp] + delta * 4);
+		if (bc->codec == ORC_BS_V3DC) {
+			if (delta < -0x80) delta += 0x100;
+			else if (delta > 0x80) delta -= 0x100;
+		}
+		const uint32_t w = L->dc[(comp << 9) | (delta & 0x1FF)];
+		if (!L->dc_valid[(comp << 9) | (delta & 0x1FF)]) return -1;   /* reference reads uninitialised memory here */
+		if (!sink_put(s, (int)(w >> 24), w & 0xFFFFFF)) return 0;
+	}
+
+	int run = 0;
+	for (int i = 1; i < 64; i++) {
+		const int ri = orc_zagzig[i];
+		const int ac = clamp_level(div_rounded(blk[ri], qt[ri]));
+		if (ac == 0) {
+			run++;
+			continue;
+		}
+		const uint32_t w = L->ac[(run << 10) | (ac & 0x3FF)];
+		if (!sink_put(s, (int)(w >> 24), w & 0xFFFFFF)) return 0;
+		run = 0;
+		bc->hwords++;
+	}
+	if (!sink_put(s, 2, 0x2)) return 0;
+	bc->block_type = (bc->block_type + 1) % 6;
+	bc->hwords += 2;
+	return 1;
+}
+
+/* mdec.c:605-643: NV21 -> six level-shifted 8x8 blocks per macroblock, then the DCT.
+ * coefs is laid out [6][mb_count][64] with mb index fy*nx+fx, as the reference stores it. */
+void orc_mdec_frame_to_coefs(int w, int h, const uint8_t *nv21, int16_t *coefs) {
+	const int nx = w / 16, ny = h / 16, nmb = nx * ny;
+	const uint8_t *yp = nv21, *cp = nv21 + w * h;
+	for (int fx = 0; fx < nx; fx++)
+		for (int fy = 0; fy < ny; fy++) {
+			int16_t *b[6];
+			for (int i = 0; i < 6; i++) b[i] = coefs + ((size_t)i * nmb + (size_t)(fy * nx + fx)) * 64;
+			for (int y = 0; y < 8; y++)
+				for (int x = 0; x < 8; x++) {
+					const int k = y * 8 + x;
+					const uint8_t *c = cp + w * (fy * 8 + y) + 2 * (fx * 8 + x);
+					const uint8_t *l = yp + w * (fy * 16 + y) + fx * 16 + x;
+					b[0][k] = (int16_t)(c[0] - 128);
+					b[1][k] = (int16_t)(c[1] - 128);
+					b[2][k] = (int16_t)(l[0] - 128);
+					b[3][k] = (int16_t)(l[8] - 128);
+					b[4][k] = (int16_t)(l[8 * w] - 128);
+					b[5][k] = (int16_t)(l[8 * w + 8] - 128);
+				}
+			for (int i = 0; i < 6; i++) orc_fdct_islow8(b[i]);
+		}
+}
+
+/* mdec.c:663-723: one rate-control attempt at a given scale.  Returns 1 fit, 0 overflow,
+ * -1 undefined DC code.  bits_out (optional) receives the attempt's bit count when it fit. */
+static int attempt(int codec, int w, int h, const int16_t *coefs, int scale, uint8_t *out, int cap,
+                   int *bytes_used, int *hwords) {
+	const struct orc_mdec_luts *L = luts();
+	const int nx = w / 16, ny = h / 16, nmb = nx * ny;
+	int16_t qt[64];
+	qt[0] = (int16_t)(orc_quant_matrix[0] * 8);
+	for (int i = 1; i < 64; i++) qt[i] = (int16_t)(orc_quant_matrix[i] * scale);
+
+	memset(out, 0, (size_t)cap);
+	bitsink_t s = {out, cap, 8, 0, 16};
+	blockcoder_t bc = {codec, 0, {0, 0, 0}, 0};
+
+	for (int fx = 0; fx < nx; fx++)
+		for (int fy = 0; fy < ny; fy++)
+			for (int i = 0; i < 6; i++) {
+				const int r = code_block(&s, &bc, L, coefs + ((size_t)i * nmb + (size_t)(fy * nx + fx)) * 64, qt);
+				if (r != 1) return r;
+			}
+	if (!sink_put(&s, 10, codec == ORC_BS_V2 ? 0x1FFu : 0x3FFu)) return 0;
+	if (!sink_flush(&s)) return 0;
+	*bytes_used = s.used;
+	*hwords = bc.hwords + 2;
+	return 1;
+}
+
+int orc_mdec_encode_frame(int codec, int w, int h, const uint8_t *nv21, int frame_max_size,
+                          uint8_t *out, orc_mdec_result_t *res) {
+	if (w <= 0 || h <= 0 || (w % 16) || (h % 16) || frame_max_size < 8) return ORC_MDEC_EINVAL;
+	const int nmb = (w / 16) * (h / 16);
+	int16_t *coefs = malloc((size_t)nmb * 6 * 64 * sizeof(int16_t));
+	if (!coefs) return ORC_MDEC_EINVAL;
+	orc_mdec_frame_to_coefs(w, h, nv21, coefs);
+
+	int scale, bytes_used = 0, hwords = 0, rc = 0;
+	for (scale = 1; scale < 64; scale++) {
+		rc = attempt(codec, w, h, coefs, scale, out, frame_max_size, &bytes_used, &hwords);
+		if (rc != 0) break;
+	}
+	free(coefs);
+	if (rc < 0) return ORC_MDEC_EDCRANGE;
+	if (scale >= 64) return ORC_MDEC_ENOFIT;   /* the reference asserts here, mdec.c:723 */
+
+	/* mdec.c:725-754 */
+	hwords = (hwords + 0x3F) & ~0x3F;
+	const int blocks_used = (hwords + 1) >> 1;
+	bytes_used = (bytes_used + 3) & ~3;
+	out[0] = (uint8_t)blocks_used;
+	out[1] = (uint8_t)(blocks_used >> 8);
+	out[2] = 0x00;
+	out[3] = 0x38;
+	out[4] = (uint8_t)scale;
+	out[5] = (uint8_t)(scale >> 8);
+	out[6] = codec == ORC_BS_V2 ? 0x02 : 0x03;
+	out[7] = 0x00;
+	if (res) {
+		res->quant_scale = scale;
+		res->bytes_used = bytes_used;
+		res->blocks_used = blocks_used;
+		res->uncomp_hwords_used = hwords;
+	}
+	return 0;
+}
+
+int orc_mdec_encode_frames(int codec, int w, int h, const uint8_t *frames, int n_frames,
+                           const int *frame_max_sizes, int out_stride, uint8_t *out,
+                           orc_mdec_result_t *res) {
+	const size_t fsz = (size_t)w * h * 3 / 2;
+	for (int i = 0; i < n_frames; i++) {
+		const int rc = orc_mdec_encode_frame(codec, w, h, frames + fsz * i, frame_max_sizes[i],
+		                                     out + (size_t)out_stride * i, res ? res + i : NULL);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * STR video-sector packetiser, mdec.c:757-836.  The reference advances the frame
+ * pointer by w*h*2 per consumed frame (mdec.c:765,778) although NV21 frames are w*h*3/2
+ * apart; like the reference's only caller we are handed exactly the frame to encode
+ * next, and the quirk is kept (it matters only if more than one frame is consumed per
+ * call, which requires a zero-byte budget).
+ * ---------------------------------------------------------------------------------- */
+int orc_mdec_encode_sector_str(orc_str_state_t *st, int codec, int w, int h, int format,
+                               uint16_t str_video_id, const uint8_t *video_frames, uint8_t *output) {
+	int frames_used = 0;
+	const size_t quirk_stride = (size_t)w * h * 2;
+
+	while (st->frame_data_offset >= st->frame_max_size) {
+		st->frame_index++;
+		st->overflow_num += st->base_overflow;
+		st->frame_max_size = st->overflow_num / st->overflow_den * 2016;
+		st->overflow_num %= st->overflow_den;
+		st->frame_data_offset = 0;
+		orc_mdec_result_t r;
+		const int rc = orc_mdec_encode_frame(codec, w, h, video_frames, st->frame_max_size, st->frame_output, &r);
+		if (rc) return rc;
+		st->bytes_used = r.bytes_used;
+		st->quant_scale_sum += r.quant_scale;
+		video_frames += quirk_stride;
+		frames_used++;
+	}
+
+	uint8_t hd[32];
+	memset(hd, 0, sizeof hd);
+	const int chunk_index = st->frame_data_offset / 2016, chunk_count = st->frame_max_size / 2016;
+	hd[0] = 0x60; hd[1] = 0x01;
+	hd[2] = (uint8_t)str_video_id; hd[3] = (uint8_t)(str_video_id >> 8);
+	hd[4] = (uint8_t)chunk_index; hd[5] = (uint8_t)(chunk_index >> 8);
+	hd[6] = (uint8_t)chunk_count; hd[7] = (uint8_t)(chunk_count >> 8);
+	for (int k = 0; k < 4; k++) {
+		hd[8 + k] = (uint8_t)((uint32_t)st->frame_index >> (8 * k));
+		hd[12 + k] = (uint8_t)((uint32_t)st->bytes_used >> (8 * k));
+	}
+	hd[16] = (uint8_t)w; hd[17] = (uint8_t)(w >> 8);
+	hd[18] = (uint8_t)h; hd[19] = (uint8_t)(h >> 8);
+	memcpy(hd + 20, st->frame_output, 8);
+
+	const int off = format == ORC_FMT_STR ? 0x08 : (format == ORC_FMT_STRCD ? 0x18 : 0x00);
+	memcpy(output + off, hd, 32);
+	memcpy(output + off + 32, st->frame_output + st->frame_data_offset, 2016);
+	st->frame_data_offset += 2016;
+	return frames_used;
+}
