@@ -1,0 +1,129 @@
+/*
+ * psxav_hip.h -- batched, device-resident extensions of the psxavenc hot path for MI355X (gfx950).
+ *
+ * The reference API encodes one frame / one 28-sample block per synchronous call
+ * (psxavenc/mdec.h:65-74, libpsxav/libpsxav.h:73-101).  A kernel launch + copy per call costs
+ * more than the work itself, so the throughput surface is batched: N frames (or N independent
+ * ADPCM chains) per call, buffers already resident in HBM, asynchronous on a caller stream.
+ * The per-call drop-in functions in psxav_mdec.h / psxav_audio.h are thin wrappers over these.
+ *
+ * Plain C ABI: pointers, sizes, ints.  Functions return 0 on success or a negative PSXHIP_E*
+ * code; psxhip_last_error() gives the text for the calling thread.  "d_" parameters are device
+ * pointers (hipMalloc / torch CUDA tensors), everything else is host memory.  `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef PSXAV_HIP_H
+#define PSXAV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	PSXHIP_OK = 0,
+	PSXHIP_EINVAL = -1,     /* bad argument (size not a multiple of 16, NULL pointer, ...) */
+	PSXHIP_EDEVICE = -2,    /* HIP runtime error / no gfx950 device */
+	PSXHIP_ENOMEM = -3,
+	PSXHIP_ENOFIT = -4      /* some frame does not fit its budget at any quant scale < 64 (the
+	                           reference asserts here, psxavenc/mdec.c:723) */
+};
+
+int psxhip_device_count(void);
+const char *psxhip_last_error(void);
+const char *psxhip_version(void);
+
+/* ---------------------------------------------------------------- MDEC BS frame encoder ---- */
+
+/* what encode_frame_bs leaves in mdec_encoder_state_t (psxavenc/mdec.c:719-736) */
+typedef struct {
+	int32_t quant_scale;         /* 1..63; 64 = no scale fits (bytes_used = 0 then) */
+	int32_t bytes_used;          /* bitstream bytes incl. the 8-byte header, rounded up to 4 */
+	int32_t blocks_used;         /* MDEC command word count */
+	int32_t uncomp_hwords_used;  /* rounded up to 64 */
+} psxhip_mdec_result_t;
+
+typedef struct psxhip_mdec_ctx psxhip_mdec_ctx_t;
+
+/* codec: 0 = BS v2, 1 = v3, 2 = v3dc (bs_codec_t, psxavenc/args.h:61-65).
+ * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 x 1024.
+ * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging). */
+int psxhip_mdec_create(psxhip_mdec_ctx_t **ctx, int device, int codec, int width, int height,
+                       int max_frame_size);
+void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
+
+/* Encode n_frames NV21 frames (frame i at d_frames + i*frame_stride, w*h*3/2 bytes each) into
+ * d_out + i*out_stride.  Exactly frame_max_size bytes are written per frame: header, bitstream,
+ * zero fill -- what psxavenc/mdec.c:676,739-754 leave in frame_output.  d_frame_max_sizes may be
+ * NULL, then every frame uses uniform_max_size.  d_frames, d_out, frame_stride and out_stride
+ * must be 4-byte aligned.  Asynchronous on `stream`; results land in d_results[i]. */
+int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t *ctx, const uint8_t *d_frames, size_t frame_stride,
+                                     int n_frames, const int32_t *d_frame_max_sizes, int uniform_max_size,
+                                     uint8_t *d_out, size_t out_stride, psxhip_mdec_result_t *d_results,
+                                     void *stream);
+
+/* Same, host buffers: H2D, kernel, D2H, synchronise.  frame_max_sizes may be NULL (uniform).
+ * Returns PSXHIP_ENOFIT if any frame could not be fitted (its result has quant_scale 64). */
+int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t *ctx, const uint8_t *frames, int n_frames,
+                                   const int32_t *frame_max_sizes, int uniform_max_size, uint8_t *out,
+                                   size_t out_stride, psxhip_mdec_result_t *results);
+
+/* Name and grid of the kernel the last encode call launched (for bench.py's roofline block). */
+const char *psxhip_mdec_kernel_name(void);
+
+/* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */
+
+/* carried state of one channel: the last two DECODED samples (libpsxav/adpcm.c:135-136).  The
+ * reference's qerr is never updated and mse is per-trial scratch (adpcm.c:107,131-132). */
+typedef struct {
+	int32_t prev1, prev2;
+} psxhip_adpcm_state_t;
+
+/* One independent encoder chain: `n_units` consecutive 28-sample sound units read from
+ * d_samples + sample_offset with stride `pitch` (int16 elements); samples at index >= sample_limit
+ * (counted in units of `pitch`, like adpcm.c:65,110) read as zero. */
+typedef struct {
+	int64_t sample_offset;   /* element offset into d_samples */
+	int32_t pitch;           /* 1 = mono / planar, 2 = interleaved stereo */
+	int32_t sample_limit;    /* valid samples in this chain from sample_offset on */
+	int32_t n_units;         /* sound units to encode */
+	int32_t reserved;
+} psxhip_adpcm_chain_t;
+
+/* Encode n_chains independent chains.  filter_count 5 (SPU) or 4 (XA); bits 4 or 8
+ * (shift range 12 / 8, adpcm.c:29-34).  Output per unit: 1 header byte
+ * ((shift & 15) | filter << 4) followed by 28 code bytes (masked to `bits` bits), i.e. 29-byte
+ * records at d_units + (unit_base[c] + u) * 32 (32-byte stride).  d_states[c] is read and updated. */
+int psxhip_adpcm_encode_chains_device(int device, const int16_t *d_samples, const psxhip_adpcm_chain_t *d_chains,
+                                      const int32_t *d_unit_base, int n_chains, int max_units, int filter_count,
+                                      int bits, psxhip_adpcm_state_t *d_states, uint8_t *d_units, void *stream);
+
+/* Pack unit records into 16-byte SPU blocks (adpcm.c:367-372): n_blocks records -> d_out. */
+int psxhip_spu_pack_device(int device, const uint8_t *d_units, int n_blocks, uint8_t *d_out, void *stream);
+
+/* Assemble XA sectors from unit records (adpcm.c:193-233,266-332): sector s of the stream takes its
+ * 18 groups x (8 | 4) units from records [s*units_per_sector ...), laid out in encode order.
+ * Writes sector_size bytes per sector (2336 .xa / 2352 XACD) incl. sync, BCD time code, subheaders
+ * and the form-2 EDC (libpsxav/cdrom.c:28-41,55-74,102-110). */
+int psxhip_xa_assemble_device(int device, const uint8_t *d_units, int n_sectors, int format, int stereo,
+                              int frequency, int bits, int file_number, int channel_number, int first_lba,
+                              uint8_t *d_out, void *stream);
+
+/* Host-buffer convenience: n_streams independent SPU streams of equal length. */
+int psxhip_spu_encode_streams_host(int device, const int16_t *samples, int n_streams, int samples_per_stream,
+                                   psxhip_adpcm_state_t *states, uint8_t *out);
+
+/* ---------------------------------------------------------------- synthetic inputs --------- */
+
+/* Integer-only generators (same function as oracle/synth.c) so benchmarks can fill HBM directly. */
+int psxhip_synth_frames_device(int device, uint8_t *d_frames, size_t frame_stride, int width, int height,
+                               uint32_t seed, uint32_t first_frame, int n_frames, int noise_amp, void *stream);
+int psxhip_synth_pcm_device(int device, int16_t *d_pcm, uint32_t seed, uint32_t chain, int64_t first_sample,
+                            int64_t n, int kind, int pitch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSXAV_HIP_H */

@@ -1,0 +1,719 @@
+// mdec_kernels.hip -- MDEC "BS" frame encoder for MI355X (gfx950), hand-written HIP.
+//
+// Replaces, for batches of frames resident in HBM, what the reference does per frame in
+// psxavenc/mdec.c:580-755 (encode_frame_bs): NV21 -> macroblocks -> 8x8 forward DCT -> quantise ->
+// zig-zag/RLE -> BS v2/v3 VLC -> bit-pack, inside the "first quant scale that fits" loop.
+//
+// Mapping (see DESIGN.md for the reasoning):
+//   * one workgroup (16 wavefronts) owns one frame at a time and loops over frames (persistent grid);
+//   * one wavefront owns one macroblock at a time: 48 lanes run the row / column DCT butterflies of
+//     the six 8x8 blocks (8x8 transposes staged in LDS), then lane k owns zig-zag position k;
+//   * quantisation is an exact integer rounding division done with one fp32 multiply (proof in
+//     quant_level()); run lengths come from a 64-bit ballot + count-leading-zeros; code lengths and
+//     codes from a (run, |level|) LUT held in LDS; bit offsets from DPP prefix sums;
+//   * the rate-control loop evaluates kScalesPerPass scales per pass over the frame's coefficients
+//     (kept as int16 in an L2-resident scratch slab) and takes the FIRST scale that fits, exactly
+//     like the reference's ascending loop (bits(s) is not provably monotone, so no bisection);
+//   * the chosen scale's bitstream is assembled in LDS with ds_or and leaves the CU as coalesced
+//     dword stores, header and zero tail included (the reference's memset, mdec.c:676).
+//
+// MFMA is deliberately not used: the DCT is the bit-exact integer "islow" butterfly (see
+// fdct8()), not a dense contraction, and everything after it is integer / bit manipulation.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bs_vlc_lut.h"
+#include "psxhip_internal.h"
+#include "wave_ops.h"
+
+namespace {
+
+constexpr int kWavesPerGroup = 16;
+constexpr int kThreads = kWavesPerGroup * 64;
+constexpr int kScalesPerPass = 4;
+constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
+
+__constant__ uint8_t c_ac_len[BS_LUT_SIZE];
+__constant__ uint16_t c_ac_code[BS_LUT_SIZE];
+__constant__ uint8_t c_zagzig[64];
+__constant__ uint8_t c_quant_zz[64];
+__constant__ uint8_t c_dc_prefix[2][8];   // [0] chroma, [1] luma
+__constant__ uint8_t c_dc_plen[2][8];
+
+struct FrameJob {
+    const uint8_t* frames;
+    size_t frame_stride;
+    int width, height, nx, ny, nmb;
+    int n_frames;
+    const int32_t* max_sizes;
+    int uniform_max_size;
+    uint8_t* out;
+    size_t out_stride;
+    psxhip_mdec_result_t* results;
+    int16_t* coef_slab;      // [gridDim.x][nmb][6][64], zig-zag order
+    int out_words;           // LDS dwords reserved for one frame's output
+};
+
+// ---------------------------------------------------------------------------------------------
+// 8-point forward DCT, IJG "jfdctint" (Loeffler-Ligtenberg-Moschytz) for 8-bit samples as
+// libavcodec specialises it (ff_jpeg_fdct_islow_8, the routine psxavenc's AVDCT call resolves to in
+// the release configuration; mdec.c:640, .github/scripts/build.sh:36-56).  13-bit constants, 4
+// fractional bits kept after the row pass.  COLUMN selects the output scaling of the second pass.
+// ---------------------------------------------------------------------------------------------
+template <bool COLUMN>
+__device__ __forceinline__ void fdct8(int (&d)[8]) {
+    constexpr int K_0_298 = 2446, K_0_390 = 3196, K_0_541 = 4433, K_0_765 = 6270, K_0_899 = 7373,
+                  K_1_175 = 9633, K_1_501 = 12299, K_1_847 = 15137, K_1_961 = 16069, K_2_053 = 16819,
+                  K_2_562 = 20995, K_3_072 = 25172;
+    constexpr int SH = COLUMN ? 13 + 4 : 13 - 4;
+    constexpr int RND = 1 << (SH - 1);
+
+    const int s07 = d[0] + d[7], s16 = d[1] + d[6], s25 = d[2] + d[5], s34 = d[3] + d[4];
+    int o0 = d[3] - d[4], o1 = d[2] - d[5], o2 = d[1] - d[6], o3 = d[0] - d[7];
+    const int e0 = s07 + s34, e3 = s07 - s34, e1 = s16 + s25, e2 = s16 - s25;
+
+    if (COLUMN) {
+        d[0] = (e0 + e1 + 8) >> 4;
+        d[4] = (e0 - e1 + 8) >> 4;
+    } else {
+        d[0] = (e0 + e1) * 16;
+        d[4] = (e0 - e1) * 16;
+    }
+    const int r = (e2 + e3) * K_0_541;
+    d[2] = (r + e3 * K_0_765 + RND) >> SH;
+    d[6] = (r - e2 * K_1_847 + RND) >> SH;
+
+    int z1 = o0 + o3, z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+    const int z5 = (z3 + z4) * K_1_175;
+    o0 *= K_0_298;
+    o1 *= K_2_053;
+    o2 *= K_3_072;
+    o3 *= K_1_501;
+    z1 *= -K_0_899;
+    z2 *= -K_2_562;
+    z3 = z3 * -K_1_961 + z5;
+    z4 = z4 * -K_0_390 + z5;
+    d[7] = (o0 + z1 + z3 + RND) >> SH;
+    d[5] = (o1 + z2 + z4 + RND) >> SH;
+    d[3] = (o2 + z2 + z3 + RND) >> SH;
+    d[1] = (o3 + z1 + z4 + RND) >> SH;
+}
+
+// wave-level ordering point for LDS traffic between lanes of the same wavefront
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantiser.  The reference computes (int)round((double)n / (double)d)  (mdec.c:438): round half
+// away from zero, i.e.  sgn(n) * floor((2|n| + d) / (2d)).   With N = 2|n| + d and D = 2d,
+// floor(N / D) == floor((N + 0.5) / D), and (N + 0.5) / D is at least 0.5 / D away from every
+// integer.  N < 2^17, so N + 0.5 is exact in fp32; one rcp (<= 1 ulp) and one multiply put the
+// product within (N + 0.5) * 1.5 * 2^-23 / D of the true quotient, which is < 0.5 / D for
+// N < 2.7e6.  Truncation therefore gives the exact floor.  `two_abs` = 2|n|, `d` = quant * scale,
+// `inv2d` = 1 / (2d).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int quant_level(int two_abs, int d, float inv2d) {
+    return (int)(((float)(two_abs + d) + 0.5f) * inv2d);
+}
+
+// DC: divisor is always 16 (mdec.c:671), clamp to [-512, 510] (mdec.c:260-267).
+__device__ __forceinline__ int quant_dc(int c0) {
+    const int a = c0 < 0 ? -c0 : c0;
+    const int q = (a + 8) >> 4;
+    const int v = c0 < 0 ? -q : q;
+    return v < -512 ? -512 : (v > 510 ? 510 : v);
+}
+
+// length in bits of the v3 DC code for a (possibly wrapped) delta; luma = 1 for Y blocks
+__device__ __forceinline__ int dc_delta_len(int delta, int luma, const uint8_t* plen /* [2][8] in LDS */) {
+    if (delta == 0) return luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
+    const int a = delta < 0 ? -delta : delta;
+    const int m = 31 - __builtin_clz((unsigned)a);
+    return plen[luma * 8 + m] + 1 + m;
+}
+
+struct Lds {
+    uint32_t* out;          // [out_words]           frame output staging, dword j = output bytes 4j..4j+3 (pre-swizzle)
+    uint16_t* mb_bits;      // [nmb][kScalesPerPass] AC bits of each macroblock at each scale of the pass
+    uint32_t* mb_off;       // [nmb]                 bit offset of each macroblock in the chosen bitstream
+    int16_t* dcq;           // [nmb*6]               quantised DC (v2) / DC delta (v3) per block, encode order
+    uint8_t* ac_len;        // [BS_LUT_SIZE]
+    uint16_t* ac_code;      // [BS_LUT_SIZE]
+    uint8_t* dc_plen;       // [16]
+    uint8_t* dc_prefix;     // [16]
+    int16_t* tiles;         // per-wave DCT staging
+    int* pass_bits;         // [kScalesPerPass] AC bits of the whole frame per scale
+    int* scalars;           // [8]: 0 dc_bits, 1 chosen scale, 2 chosen index in pass, 3 nnz, 4 total bits
+};
+
+constexpr int kWaveTileBytes = 6 * kTileStride * 2 + 6 * 64 * 2;   // transpose tile + zig-zag tile (pixel tile aliases the latter)
+
+__host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
+    size_t b = 0;
+    b += (size_t)out_words * 4;
+    b += (size_t)nmb * kScalesPerPass * 2;
+    b = (b + 3) & ~(size_t)3;
+    b += (size_t)nmb * 4;
+    b += (size_t)nmb * 6 * 2;
+    b = (b + 3) & ~(size_t)3;
+    b += BS_LUT_SIZE;             // ac_len
+    b = (b + 3) & ~(size_t)3;
+    b += BS_LUT_SIZE * 2;         // ac_code
+    b += 32;                      // dc tables
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    b += 64;                      // pass_bits + scalars
+    return b;
+}
+
+__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words) {
+    Lds L;
+    size_t b = 0;
+    L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
+    L.mb_bits = (uint16_t*)(base + b);    b += (size_t)nmb * kScalesPerPass * 2;  b = (b + 3) & ~(size_t)3;
+    L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
+    L.dcq = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
+    L.ac_len = (uint8_t*)(base + b);      b += BS_LUT_SIZE;                        b = (b + 3) & ~(size_t)3;
+    L.ac_code = (uint16_t*)(base + b);    b += BS_LUT_SIZE * 2;
+    L.dc_plen = (uint8_t*)(base + b);     b += 16;
+    L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
+    L.tiles = (int16_t*)(base + b);       b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    L.pass_bits = (int*)(base + b);       b += kScalesPerPass * 4;
+    L.scalars = (int*)(base + b);
+    return L;
+}
+
+// OR `len` bits (value `v`, MSB first) into the staging buffer at bit position `pos` of the
+// bitstream.  Staging dword j holds stream bits [32j, 32j+32) with bit 32j in its MSB.
+__device__ __forceinline__ void put_bits(uint32_t* words, uint32_t pos, int len, uint32_t v) {
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    const uint64_t t = (uint64_t)v << (64 - sh - len);
+    const uint32_t hi = (uint32_t)(t >> 32), lo = (uint32_t)t;
+    atomicOr(&words[w], hi);
+    if (lo) atomicOr(&words[w + 1], lo);
+}
+
+// Per-lane constants of the AC path: lane k owns zig-zag position k.
+struct LaneConst {
+    int quant;          // quant matrix entry at this zig-zag position
+    uint64_t below;     // mask of lanes below this one
+};
+
+// AC bits of one block at one scale; also returns the ballot of non-zero levels (wave-uniform).
+// coef is this lane's coefficient; lane 0 (DC) never participates.
+__device__ __forceinline__ int ac_block_bits(int two_abs, bool neg, int d, float inv2d, const LaneConst& lc,
+                                             const uint8_t* ac_len, int lane, uint64_t& mask_out, int& level_out,
+                                             int& run_out) {
+    int q = quant_level(two_abs, d, inv2d);
+    const int lim = neg ? 512 : 510;
+    q = q > lim ? lim : q;
+    const bool nz = (q != 0) && (lane != 0);
+    const uint64_t mask = wave::ballot(nz);
+    const uint64_t prev = (mask & lc.below) | 1ull;            // bit 0 = the DC slot, acts as "previous coefficient" sentinel
+    const int run = lane - 1 - (63 - __builtin_clzll(prev));
+    int len = 0;
+    if (nz) {
+        len = BS_ESCAPE_BITS;
+        if (run <= BS_LUT_MAX_RUN && q <= BS_LUT_MAX_LEVEL) {
+            const int l = ac_len[run * BS_LUT_W + q];
+            len = l ? l : BS_ESCAPE_BITS;
+        }
+    }
+    mask_out = mask;
+    level_out = q;
+    run_out = run;
+    return len;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int CODEC>
+__global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const FrameJob job) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Lds L = carve(smem, job.nmb, job.out_words);
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
+    const int nblk = nmb * 6;
+
+    // ---- once per workgroup: LUTs into LDS, per-lane constants
+    for (int i = tid; i < BS_LUT_SIZE; i += kThreads) {
+        L.ac_len[i] = c_ac_len[i];
+        L.ac_code[i] = c_ac_code[i];
+    }
+    if (tid < 16) {
+        L.dc_plen[tid] = c_dc_plen[tid >> 3][tid & 7];
+        L.dc_prefix[tid] = c_dc_prefix[tid >> 3][tid & 7];
+    }
+    LaneConst lc;
+    lc.quant = c_quant_zz[lane];
+    lc.below = (1ull << lane) - 1ull;
+
+    // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3)
+    int zpos[8];
+    {
+        // raster position -> scan position, built from the scan table
+        // (64 lanes: lane k knows c_zagzig[k]; invert through LDS once)
+        uint8_t* inv = (uint8_t*)L.tiles;   // temporary use before the tiles are live
+        if (tid < 64) inv[c_zagzig[tid]] = (uint8_t)tid;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 8; v++) zpos[v] = inv[v * 8 + (lane & 7)];
+        __syncthreads();
+    }
+
+    int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
+    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][64] zig-zag ordered coefficients
+    uint32_t* pix32 = (uint32_t*)tileZ;                                // [6][8][2] dwords of source pixels (aliases tileZ)
+    uint16_t* pix16 = (uint16_t*)tileZ;
+
+    int16_t* slab = job.coef_slab + (size_t)blockIdx.x * nmb * 384;
+
+    for (int f = (int)blockIdx.x; f < job.n_frames; f += (int)gridDim.x) {
+        const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
+        const int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
+        const int max_words = (max_size + 3) >> 2;
+
+        // ---- reset per-frame state
+        for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
+        if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
+        if (tid < 8) L.scalars[tid] = 0;
+        __syncthreads();
+
+        // =====================================================================================
+        // Pass 1: DCT of every macroblock + AC bit counts for scales 1..kScalesPerPass
+        // =====================================================================================
+        int dq[kScalesPerPass];
+        float inv[kScalesPerPass];
+#pragma unroll
+        for (int s = 0; s < kScalesPerPass; s++) {
+            dq[s] = lc.quant * (1 + s);
+            inv[s] = 1.0f / (float)(2 * dq[s]);
+        }
+        int wave_tot[kScalesPerPass];
+#pragma unroll
+        for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
+
+        for (int m = wid; m < nmb; m += kWavesPerGroup) {
+            const int fy = m / nx, fx = m - fy * nx;
+            const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
+
+            // -- gather the macroblock's 384 source bytes (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
+            {
+                const int row = lane >> 2, c4 = lane & 3;
+                const uint8_t* yp = frame + (size_t)(fy * 16 + row) * W + fx * 16 + c4 * 4;
+                const uint32_t yd = *(const uint32_t*)yp;
+                const int blk = 2 + ((row >> 3) << 1) + (c4 >> 1);
+                pix32[(blk * 8 + (row & 7)) * 2 + (c4 & 1)] = yd;
+                if (lane < 32) {
+                    const uint8_t* cp = frame + (size_t)W * H + (size_t)(fy * 8 + row) * W + fx * 16 + c4 * 4;
+                    const uint32_t cd = *(const uint32_t*)cp;
+                    const uint32_t cr = (cd & 0xFFu) | ((cd >> 8) & 0xFF00u);
+                    const uint32_t cb = ((cd >> 8) & 0xFFu) | ((cd >> 16) & 0xFF00u);
+                    pix16[(0 * 8 + row) * 4 + c4] = (uint16_t)cr;
+                    pix16[(1 * 8 + row) * 4 + c4] = (uint16_t)cb;
+                }
+            }
+            wave_sync();
+
+            const int blk = lane >> 3, r8 = lane & 7;
+            int d[8];
+            if (lane < 48) {
+                // -- row pass: lane = (block, row)
+                const uint2 p = *(const uint2*)&pix32[(blk * 8 + r8) * 2];
+                d[0] = (int)(p.x & 0xFF) - 128;
+                d[1] = (int)((p.x >> 8) & 0xFF) - 128;
+                d[2] = (int)((p.x >> 16) & 0xFF) - 128;
+                d[3] = (int)(p.x >> 24) - 128;
+                d[4] = (int)(p.y & 0xFF) - 128;
+                d[5] = (int)((p.y >> 8) & 0xFF) - 128;
+                d[6] = (int)((p.y >> 16) & 0xFF) - 128;
+                d[7] = (int)(p.y >> 24) - 128;
+                fdct8<false>(d);
+#pragma unroll
+                for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+            }
+            wave_sync();
+            if (lane < 48) {
+                // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
+                const int4 q = *(const int4*)&tileT[blk * kTileStride + r8 * 8];
+                d[0] = (int)(int16_t)(q.x & 0xFFFF);
+                d[1] = q.x >> 16;
+                d[2] = (int)(int16_t)(q.y & 0xFFFF);
+                d[3] = q.y >> 16;
+                d[4] = (int)(int16_t)(q.z & 0xFFFF);
+                d[5] = q.z >> 16;
+                d[6] = (int)(int16_t)(q.w & 0xFFFF);
+                d[7] = q.w >> 16;
+                fdct8<true>(d);
+#pragma unroll
+                for (int v = 0; v < 8; v++) tileZ[blk * 64 + zpos[v]] = (int16_t)d[v];
+            }
+            wave_sync();
+
+            // -- lane k now owns zig-zag position k of each of the 6 blocks
+            int coef[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) coef[b] = tileZ[b * 64 + lane];
+            wave_sync();   // tileZ is the next iteration's pixel tile
+
+            int16_t* dst = slab + (size_t)mbe * 384 + lane;
+#pragma unroll
+            for (int b = 0; b < 6; b++) dst[b * 64] = (int16_t)coef[b];
+
+            if (lane == 0) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) L.dcq[mbe * 6 + b] = (int16_t)quant_dc(coef[b]);
+            }
+
+            int acc[kScalesPerPass];
+#pragma unroll
+            for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const int a = coef[b] < 0 ? -coef[b] : coef[b];
+                const bool neg = coef[b] < 0;
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) {
+                    uint64_t mask;
+                    int lvl, run;
+                    acc[s] += ac_block_bits(2 * a, neg, dq[s], inv[s], lc, L.ac_len, lane, mask, lvl, run);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kScalesPerPass; s++) {
+                const int t = wave::reduce_add(acc[s]);
+                wave_tot[s] += t;
+                if (lane == 0) L.mb_bits[mbe * kScalesPerPass + s] = (uint16_t)t;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
+        }
+        __syncthreads();
+
+        // =====================================================================================
+        // DC: v2 = 10 bits per block; v3 = DPCM chain per component in encode order (mdec.c:454-479)
+        // =====================================================================================
+        if (CODEC == 0) {
+            if (tid == 0) L.scalars[0] = 10 * nblk;
+        } else if (wid < 3) {
+            // wave 0: Cr chain, wave 1: Cb chain, wave 2: the Y chain (4 blocks per macroblock).
+            // Element i maps last -> new_last:
+            //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
+            //   dc % 4 == 2 : last < dc ? dc + 2 : dc - 2           (tie, rounds away from zero)
+            // Both are step functions (thr, lo, hi); composition g(f(x)) = (thr_f, g(lo_f), g(hi_f)),
+            // so the chain is an inclusive scan under composition.
+            const int count = wid == 2 ? 4 * nmb : nmb;
+            int carry = 0, bits = 0;
+            for (int base = 0; base < count; base += 64) {
+                const int i = base + lane;
+                const bool live = i < count;
+                const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
+                const int dc = live ? (int)L.dcq[idx] : 0;
+                int thr, lo, hi;
+                if ((dc & 3) == 2) {
+                    thr = dc; lo = dc + 2; hi = dc - 2;
+                } else {
+                    const int a = dc < 0 ? -dc : dc;
+                    const int rq = ((a + 2) >> 2) << 2;
+                    thr = 0; lo = hi = dc < 0 ? -rq : rq;
+                }
+                if (!live) { thr = -100000; lo = hi = 0; }   // identity is never needed: dead lanes sit after all live ones
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int pthr = __shfl_up(thr, off, 64);
+                    const int plo = __shfl_up(lo, off, 64);
+                    const int phi = __shfl_up(hi, off, 64);
+                    if (lane >= off) {
+                        // me(prev(x)): apply my current (thr, lo, hi) to the predecessor's two outputs
+                        const int nlo = plo < thr ? lo : hi;
+                        const int nhi = phi < thr ? lo : hi;
+                        thr = pthr; lo = nlo; hi = nhi;
+                    }
+                }
+                const int cur = carry < thr ? lo : hi;            // last value after element i
+                int prev = __shfl_up(cur, 1, 64);
+                if (lane == 0) prev = carry;
+                int delta = (cur - prev) >> 2;                      // exact: both multiples of 4
+                if (CODEC == 2) {                                   // v3dc wrap (mdec.c:469-474)
+                    if (delta < -0x80) delta += 0x100;
+                    else if (delta > 0x80) delta -= 0x100;
+                }
+                if (live) {
+                    L.dcq[idx] = (int16_t)delta;
+                    bits += dc_delta_len(delta, wid == 2, L.dc_plen);
+                }
+                carry = __shfl(cur, 63, 64);
+                if (base + 64 > count) break;
+            }
+            bits = wave::reduce_add(bits);
+            if (lane == 0) atomicAdd(&L.scalars[0], bits);
+        }
+        __syncthreads();
+
+        // =====================================================================================
+        // Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723)
+        // =====================================================================================
+        int scale0 = 1;   // first scale of the current pass
+        for (;;) {
+            if (tid == 0) {
+                const int fixed = L.scalars[0] + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
+                int chosen = 0;
+                for (int s = 0; s < kScalesPerPass && scale0 + s < 64; s++) {
+                    const int bits = L.pass_bits[s] + fixed;
+                    if (8 + 2 * ((bits + 15) >> 4) <= max_size) {
+                        chosen = scale0 + s;
+                        L.scalars[2] = s;
+                        L.scalars[4] = bits;
+                        break;
+                    }
+                }
+                L.scalars[1] = chosen;
+            }
+            __syncthreads();
+            if (L.scalars[1] != 0 || scale0 + kScalesPerPass >= 64) break;
+            __syncthreads();
+
+            // ---- next pass: scales scale0+K .. scale0+2K-1 from the coefficient slab
+            scale0 += kScalesPerPass;
+            if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < kScalesPerPass; s++) {
+                dq[s] = lc.quant * (scale0 + s);
+                inv[s] = 1.0f / (float)(2 * dq[s]);
+                wave_tot[s] = 0;
+            }
+            for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
+                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                int acc[kScalesPerPass];
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    const int c = src[b * 64];
+                    const int a = c < 0 ? -c : c;
+#pragma unroll
+                    for (int s = 0; s < kScalesPerPass; s++) {
+                        uint64_t mask;
+                        int lvl, run;
+                        acc[s] += ac_block_bits(2 * a, c < 0, dq[s], inv[s], lc, L.ac_len, lane, mask, lvl, run);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) {
+                    const int t = wave::reduce_add(acc[s]);
+                    wave_tot[s] += t;
+                    if (lane == 0) L.mb_bits[mbe * kScalesPerPass + s] = (uint16_t)t;
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
+            }
+            __syncthreads();
+        }
+
+        const int scale = L.scalars[1];
+        uint8_t* outp = job.out + (size_t)f * job.out_stride;
+
+        if (scale == 0) {
+            // nothing fits (the reference asserts, mdec.c:723): zero output, flag the result
+            for (int i = tid; i < max_size; i += kThreads) outp[i] = 0;
+            if (tid == 0) {
+                psxhip_mdec_result_t r;
+                r.quant_scale = 64; r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
+                job.results[f] = r;
+            }
+            __syncthreads();
+            continue;
+        }
+        const int sidx = L.scalars[2];
+
+        // =====================================================================================
+        // Bit offsets of the macroblocks: exclusive scan in encode order (wave 0)
+        // =====================================================================================
+        if (wid == 0) {
+            uint32_t carry = 0;
+            for (int base = 0; base < nmb; base += 64) {
+                const int mbe = base + lane;
+                int bits = 0;
+                if (mbe < nmb) {
+                    bits = L.mb_bits[mbe * kScalesPerPass + sidx] + 12;   // six end-of-block codes
+                    if (CODEC == 0) {
+                        bits += 60;
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 6; b++) bits += dc_delta_len(L.dcq[mbe * 6 + b], b >= 2, L.dc_plen);
+                    }
+                }
+                const int incl = wave::inclusive_scan_add(bits);
+                if (mbe < nmb) L.mb_off[mbe] = carry + (uint32_t)(incl - bits);
+                carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        __syncthreads();
+
+        // =====================================================================================
+        // Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer
+        // =====================================================================================
+        {
+            const int d1 = lc.quant * scale;
+            const float inv1 = 1.0f / (float)(2 * d1);
+            uint32_t* stream = L.out + 2;      // bitstream starts at byte 8 (mdec.c:686)
+            int nnz = 0;
+            for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
+                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                uint32_t pos = L.mb_off[mbe];
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    const int c = src[b * 64];
+                    const int a = c < 0 ? -c : c;
+                    uint64_t mask;
+                    int lvl, run;
+                    int len = ac_block_bits(2 * a, c < 0, d1, inv1, lc, L.ac_len, lane, mask, lvl, run);
+                    uint32_t code = 0;
+                    if (len == BS_ESCAPE_BITS) {
+                        const int sl = c < 0 ? -lvl : lvl;
+                        code = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
+                    } else if (len) {
+                        code = (uint32_t)L.ac_code[run * BS_LUT_W + lvl] | (c < 0 ? 1u : 0u);
+                    }
+                    if (lane == 0) {
+                        // DC code (lane 0 never carries an AC code)
+                        const int dcv = L.dcq[mbe * 6 + b];
+                        if (CODEC == 0) {
+                            len = 10;
+                            code = (uint32_t)dcv & 0x3FFu;
+                        } else {
+                            const int luma = b >= 2;
+                            if (dcv == 0) {
+                                len = luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
+                                code = luma ? BS_DC_LUMA_ZERO_CODE : BS_DC_CHROMA_ZERO_CODE;
+                            } else {
+                                const int ad = dcv < 0 ? -dcv : dcv;
+                                const int mm = 31 - __builtin_clz((unsigned)ad);
+                                const uint32_t j = dcv > 0 ? (uint32_t)(dcv - (1 << mm)) : (uint32_t)(dcv + ((2 << mm) - 1));
+                                len = L.dc_plen[luma * 8 + mm] + 1 + mm;
+                                code = ((uint32_t)L.dc_prefix[luma * 8 + mm] << (mm + 1)) | ((dcv > 0 ? 1u : 0u) << mm) | j;
+                            }
+                        }
+                    }
+                    const int incl = wave::inclusive_scan_add(len);
+                    if (len) put_bits(stream, pos + (uint32_t)(incl - len), len, code);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                    if (lane == 63) put_bits(stream, pos + total, 2, 0x2u);   // end of block (mdec.c:501-503)
+                    pos += total + 2;
+                    nnz += (int)__builtin_popcountll(mask);
+                }
+            }
+            if (lane == 0) atomicAdd(&L.scalars[3], nnz);
+        }
+        __syncthreads();
+
+        // ---- end-of-frame code, header, results (mdec.c:710-754)
+        const int total_bits = L.scalars[4];
+        if (tid == 0) {
+            put_bits(L.out + 2, (uint32_t)(total_bits - 10), 10, CODEC == 0 ? 0x1FFu : 0x3FFu);
+            int hwords = L.scalars[3] + 2 * nblk + 2;
+            hwords = (hwords + 0x3F) & ~0x3F;
+            const int blocks_used = (hwords + 1) >> 1;
+            int bytes_used = 8 + 2 * ((total_bits + 15) >> 4);
+            bytes_used = (bytes_used + 3) & ~3;
+            // header dwords are stored pre-swizzle like the rest: final dword = rotate16(staging)
+            const uint32_t h0 = ((uint32_t)blocks_used & 0xFFFFu) | (0x3800u << 16);
+            const uint32_t h1 = ((uint32_t)scale & 0xFFFFu) | ((CODEC == 0 ? 2u : 3u) << 16);
+            L.out[0] = (h0 >> 16) | (h0 << 16);
+            L.out[1] = (h1 >> 16) | (h1 << 16);
+            psxhip_mdec_result_t r;
+            r.quant_scale = scale; r.bytes_used = bytes_used; r.blocks_used = blocks_used; r.uncomp_hwords_used = hwords;
+            job.results[f] = r;
+        }
+        __syncthreads();
+
+        // ---- write-out: staging dword holds two MSB-first 16-bit words; each word is stored low byte
+        //      first (mdec.c:321-333), i.e. the output dword is the staging dword rotated by 16.
+        {
+            const int full = max_size >> 2;
+            uint32_t* o32 = (uint32_t*)outp;
+            for (int i = tid; i < full; i += kThreads) {
+                const uint32_t v = L.out[i];
+                o32[i] = (v >> 16) | (v << 16);
+            }
+            const int tail = max_size & 3;
+            if (tid < tail) {
+                const uint32_t v = L.out[full];
+                const uint32_t o = (v >> 16) | (v << 16);
+                outp[full * 4 + tid] = (uint8_t)(o >> (8 * tid));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Host side of the kernel (called from psxhip_mdec.cpp through psxhip_internal.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t psxhip_mdec_lds_bytes(int nmb, int out_words) { return lds_bytes(nmb, out_words); }
+extern "C" size_t psxhip_mdec_slab_bytes_per_group(int nmb) { return (size_t)nmb * 384 * sizeof(int16_t); }
+extern "C" int psxhip_mdec_threads_per_group(void) { return kThreads; }
+
+extern "C" hipError_t psxhip_mdec_upload_tables(void) {
+    hipError_t e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ac_len), bs_ac_len_lut, sizeof(bs_ac_len_lut))) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ac_code), bs_ac_code_lut, sizeof(bs_ac_code_lut))) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_zagzig), bs_zagzig, sizeof(bs_zagzig))) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_quant_zz), bs_quant_zz, sizeof(bs_quant_zz))) != hipSuccess) return e;
+    uint8_t pre[2][8], pl[2][8];
+    for (int i = 0; i < 8; i++) {
+        pre[0][i] = bs_dc_chroma_prefix[i]; pl[0][i] = bs_dc_chroma_plen[i];
+        pre[1][i] = bs_dc_luma_prefix[i];   pl[1][i] = bs_dc_luma_plen[i];
+    }
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_dc_prefix), pre, sizeof(pre))) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_dc_plen), pl, sizeof(pl))) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
+    FrameJob job;
+    job.frames = a->d_frames;
+    job.frame_stride = a->frame_stride;
+    job.width = a->width;
+    job.height = a->height;
+    job.nx = a->width / 16;
+    job.ny = a->height / 16;
+    job.nmb = job.nx * job.ny;
+    job.n_frames = a->n_frames;
+    job.max_sizes = a->d_max_sizes;
+    job.uniform_max_size = a->uniform_max_size;
+    job.out = a->d_out;
+    job.out_stride = a->out_stride;
+    job.results = a->d_results;
+    job.coef_slab = a->d_coef_slab;
+    job.out_words = a->out_words;
+    const size_t lds = lds_bytes(job.nmb, job.out_words);
+    const dim3 grid((unsigned)a->grid), block(kThreads);
+    hipStream_t st = (hipStream_t)a->stream;
+    switch (a->codec) {
+    case 0: hipLaunchKernelGGL(mdec_encode_frames_kernel<0>, grid, block, lds, st, job); break;
+    case 1: hipLaunchKernelGGL(mdec_encode_frames_kernel<1>, grid, block, lds, st, job); break;
+    default: hipLaunchKernelGGL(mdec_encode_frames_kernel<2>, grid, block, lds, st, job); break;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes) {
+    switch (codec) {
+    case 0: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    case 1: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    default: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
+}

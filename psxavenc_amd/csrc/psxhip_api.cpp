@@ -1,0 +1,255 @@
+// psxhip_api.cpp -- the C-ABI layer of libpsxav_hip.so (include/psxav_hip.h): contexts, stream/
+// buffer plumbing and kernel launches.  No algorithmic work happens on the host here, and there is
+// no CPU fallback: without a gfx950 device every entry point fails with PSXHIP_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "psxhip_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::mutex g_tables_mu;
+bool g_tables_ready[64] = {false};
+
+#define HIP_TRY(expr, code)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            psxhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (code);                                                                    \
+        }                                                                                     \
+    } while (0)
+
+int ensure_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        psxhip_set_error("no HIP device visible (libpsxav_hip has no CPU fallback)");
+        return PSXHIP_EDEVICE;
+    }
+    if (device < 0 || device >= n || device >= 64) {
+        psxhip_set_error("device %d out of range (%d visible)", device, n);
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(device), PSXHIP_EDEVICE);
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    if (!g_tables_ready[device]) {
+        HIP_TRY(psxhip_mdec_upload_tables(), PSXHIP_EDEVICE);
+        g_tables_ready[device] = true;
+    }
+    return PSXHIP_OK;
+}
+
+}  // namespace
+
+extern "C" void psxhip_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* psxhip_last_error(void) { return g_err; }
+extern "C" const char* psxhip_version(void) { return "psxav_hip 0.1 (gfx950)"; }
+
+extern "C" int psxhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int psxhip_ensure_device(int device) { return ensure_device(device); }
+
+// ------------------------------------------------------------------------------------------ MDEC
+
+struct psxhip_mdec_ctx {
+    int device, codec, width, height, nmb;
+    int max_frame_size, out_words;
+    int groups_max;            // persistent grid size: compute units x resident groups per CU
+    size_t lds_bytes;
+    int16_t* d_slab;
+    // host-path staging
+    hipStream_t stream;
+    uint8_t* d_frames;
+    uint8_t* d_out;
+    psxhip_mdec_result_t* d_res;
+    int32_t* d_sizes;
+    int cap_frames;
+    size_t cap_out_stride;
+};
+
+extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec, int width, int height,
+                                  int max_frame_size) {
+    if (!out) return PSXHIP_EINVAL;
+    *out = nullptr;
+    if (codec < 0 || codec > 2 || width <= 0 || height <= 0 || (width % 16) || (height % 16) || width > 1024 ||
+        height > 1024 || max_frame_size < 8) {
+        psxhip_set_error("bad MDEC geometry: codec %d, %dx%d, budget %d", codec, width, height, max_frame_size);
+        return PSXHIP_EINVAL;
+    }
+    int rc = ensure_device(device);
+    if (rc) return rc;
+
+    psxhip_mdec_ctx* c = (psxhip_mdec_ctx*)calloc(1, sizeof(*c));
+    if (!c) return PSXHIP_ENOMEM;
+    c->device = device;
+    c->codec = codec;
+    c->width = width;
+    c->height = height;
+    c->nmb = (width / 16) * (height / 16);
+    c->max_frame_size = max_frame_size;
+    c->out_words = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
+    c->lds_bytes = psxhip_mdec_lds_bytes(c->nmb, c->out_words);
+
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
+    if (c->lds_bytes > (size_t)prop.maxSharedMemoryPerMultiProcessor) {
+        psxhip_set_error("frame budget %d with %d macroblocks needs %zu B of LDS (> %zu)", max_frame_size, c->nmb,
+                         c->lds_bytes, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+        free(c);
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(psxhip_mdec_set_max_lds(codec, c->lds_bytes), PSXHIP_EDEVICE);
+    int per_cu = (int)((size_t)prop.maxSharedMemoryPerMultiProcessor / c->lds_bytes);
+    const int by_threads = prop.maxThreadsPerMultiProcessor / psxhip_mdec_threads_per_group();
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    c->groups_max = prop.multiProcessorCount * per_cu;
+
+    const size_t slab = psxhip_mdec_slab_bytes_per_group(c->nmb) * (size_t)c->groups_max;
+    HIP_TRY(hipMalloc((void**)&c->d_slab, slab), PSXHIP_ENOMEM);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    *out = c;
+    return PSXHIP_OK;
+}
+
+extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_slab) (void)hipFree(c->d_slab);
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_res) (void)hipFree(c->d_res);
+    if (c->d_sizes) (void)hipFree(c->d_sizes);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+}
+
+extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint8_t* d_frames, size_t frame_stride,
+                                                int n_frames, const int32_t* d_frame_max_sizes,
+                                                int uniform_max_size, uint8_t* d_out, size_t out_stride,
+                                                psxhip_mdec_result_t* d_results, void* stream) {
+    if (!c || !d_frames || !d_out || !d_results || n_frames < 0) {
+        psxhip_set_error("encode_frames_device: NULL argument");
+        return PSXHIP_EINVAL;
+    }
+    if (n_frames == 0) return PSXHIP_OK;
+    const size_t fsz = (size_t)c->width * c->height * 3 / 2;
+    if (frame_stride < fsz || (frame_stride & 3) || (out_stride & 3) || ((uintptr_t)d_frames & 3) ||
+        ((uintptr_t)d_out & 3)) {
+        psxhip_set_error("encode_frames_device: strides / pointers must be 4-byte aligned and frame_stride >= w*h*3/2");
+        return PSXHIP_EINVAL;
+    }
+    if (!d_frame_max_sizes && (uniform_max_size < 8 || uniform_max_size > c->max_frame_size ||
+                               (size_t)uniform_max_size > out_stride)) {
+        psxhip_set_error("encode_frames_device: frame_max_size %d outside [8, %d] or larger than out_stride",
+                         uniform_max_size, c->max_frame_size);
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    psxhip_mdec_launch_t a;
+    a.d_frames = d_frames;
+    a.frame_stride = frame_stride;
+    a.width = c->width;
+    a.height = c->height;
+    a.codec = c->codec;
+    a.n_frames = n_frames;
+    a.d_max_sizes = d_frame_max_sizes;
+    a.uniform_max_size = uniform_max_size;
+    a.d_out = d_out;
+    a.out_stride = out_stride;
+    a.d_results = d_results;
+    a.d_coef_slab = c->d_slab;
+    a.out_words = c->out_words;
+    a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
+    a.stream = stream;
+    HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_t* frames, int n_frames,
+                                              const int32_t* frame_max_sizes, int uniform_max_size, uint8_t* out,
+                                              size_t out_stride, psxhip_mdec_result_t* results) {
+    if (!c || !frames || !out || !results || n_frames < 0) {
+        psxhip_set_error("encode_frames_host: NULL argument");
+        return PSXHIP_EINVAL;
+    }
+    if (n_frames == 0) return PSXHIP_OK;
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    const size_t fsz = (size_t)c->width * c->height * 3 / 2;
+    int max_size = uniform_max_size;
+    if (frame_max_sizes) {
+        max_size = 0;
+        for (int i = 0; i < n_frames; i++) {
+            if (frame_max_sizes[i] < 8 || frame_max_sizes[i] > c->max_frame_size) {
+                psxhip_set_error("encode_frames_host: frame %d budget %d outside [8, %d]", i, frame_max_sizes[i],
+                                 c->max_frame_size);
+                return PSXHIP_EINVAL;
+            }
+            if (frame_max_sizes[i] > max_size) max_size = frame_max_sizes[i];
+        }
+    }
+    if ((size_t)max_size > out_stride) {
+        psxhip_set_error("encode_frames_host: out_stride %zu smaller than the largest budget %d", out_stride, max_size);
+        return PSXHIP_EINVAL;
+    }
+    const size_t dstride = ((size_t)max_size + 3) & ~(size_t)3;
+    if (n_frames > c->cap_frames || dstride > c->cap_out_stride) {
+        const int cap = n_frames > c->cap_frames ? n_frames : c->cap_frames;
+        const size_t os = dstride > c->cap_out_stride ? dstride : c->cap_out_stride;
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        if (c->d_out) (void)hipFree(c->d_out);
+        if (c->d_res) (void)hipFree(c->d_res);
+        if (c->d_sizes) (void)hipFree(c->d_sizes);
+        c->d_frames = nullptr; c->d_out = nullptr; c->d_res = nullptr; c->d_sizes = nullptr;
+        c->cap_frames = 0;
+        c->cap_out_stride = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_frames, fsz * cap), PSXHIP_ENOMEM);
+        HIP_TRY(hipMalloc((void**)&c->d_out, os * cap), PSXHIP_ENOMEM);
+        HIP_TRY(hipMalloc((void**)&c->d_res, sizeof(psxhip_mdec_result_t) * cap), PSXHIP_ENOMEM);
+        HIP_TRY(hipMalloc((void**)&c->d_sizes, sizeof(int32_t) * cap), PSXHIP_ENOMEM);
+        c->cap_frames = cap;
+        c->cap_out_stride = os;
+    }
+    // rows are copied back max_size wide; bytes past a frame's own (smaller) budget read as zero
+    if (frame_max_sizes)
+        HIP_TRY(hipMemsetAsync(c->d_out, 0, c->cap_out_stride * (size_t)n_frames, c->stream), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fsz * n_frames, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
+    if (frame_max_sizes)
+        HIP_TRY(hipMemcpyAsync(c->d_sizes, frame_max_sizes, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice, c->stream),
+                PSXHIP_EDEVICE);
+    int rc = psxhip_mdec_encode_frames_device(c, c->d_frames, fsz, n_frames, frame_max_sizes ? c->d_sizes : nullptr,
+                                              uniform_max_size, c->d_out, c->cap_out_stride, c->d_res, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(out, out_stride, c->d_out, c->cap_out_stride, (size_t)max_size, (size_t)n_frames,
+                             hipMemcpyDeviceToHost, c->stream),
+            PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(results, c->d_res, sizeof(psxhip_mdec_result_t) * n_frames, hipMemcpyDeviceToHost, c->stream),
+            PSXHIP_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+    for (int i = 0; i < n_frames; i++)
+        if (results[i].quant_scale >= 64) {
+            psxhip_set_error("frame %d does not fit %d bytes at any quant scale", i,
+                             frame_max_sizes ? frame_max_sizes[i] : uniform_max_size);
+            return PSXHIP_ENOFIT;
+        }
+    return PSXHIP_OK;
+}
+
+extern "C" const char* psxhip_mdec_kernel_name(void) { return "mdec_encode_frames_kernel"; }
