@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- BS-v2 320x240 frames/sec on MI355X (BASELINE.json metric, config "sbs v2").
+
+One "step" = one pass of the hot path over one batch: N_FRAMES synthetic NV21 frames already resident
+in HBM -> psxhip_mdec_encode_frames_device -> N_FRAMES x 8192-byte BS frames + results in HBM.
+Multi-GPU: one process per GPU (torchrun), frames sharded by rank with no data-path collective; RCCL
+is used only for the start/stop barrier and the max-over-ranks reduction of the elapsed time (weak
+scaling: every rank encodes its own N_FRAMES).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      algorithmic bytes (w*h*3/2 read + budget written per frame) / mean kernel time from HIP
+                events on the launch stream, against the 8 TB/s HBM peak
+  cpu_baseline  oracle/ (this repo's CPU restatement of the reference path, "port") timed on one host core
+                on a bounded sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (config 'sbs v2': 1000)")
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--budget", type=int, default=8192, help="frame_max_size = sbs alignment (args.c:184)")
+    ap.add_argument("--codec", type=int, default=0, help="0 = BS v2, 1 = v3, 2 = v3dc")
+    ap.add_argument("--amp", type=int, default=4, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from psxavenc_amd import synth
+    from psxavenc_amd.mdec import MdecEncoder
+    from psxavenc_amd.parallel import shard_range
+
+    w, h, budget, n = args.width, args.height, args.budget, args.frames
+    first, count = shard_range(n * world, rank, world)     # contiguous frame ranges per rank
+    assert count == n
+    enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+    d_frames = synth.frames_device(w, h, args.seed, first, n, args.amp, device=local_rank)
+    ostride = (budget + 3) & ~3
+    d_out = torch.zeros((n, ostride), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        enc.encode_frames_device(d_frames, budget, d_out=d_out, d_results=d_res)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+
+    # ---- post-timing: every rank checks its results are sane; rank 0 diffs a sample against the oracle
+    res = d_res.cpu().numpy()
+    ok_local = bool(((res[:, 0] >= 1) & (res[:, 0] <= 63)).all())
+    parity = None
+    cpu_baseline = None
+    if rank == 0:
+        import oracle_lib as O
+        k = min(args.check_frames, n)
+        idx = np.linspace(0, n - 1, k).astype(np.int64)
+        fr = d_frames[torch.from_numpy(idx).to(dev)].cpu().numpy()
+        want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
+        got = d_out[torch.from_numpy(idx).to(dev)].cpu().numpy()[:, :budget]
+        parity = {"frames_checked": int(k), "bit_exact": bool(rc == 0 and np.array_equal(got, want) and np.array_equal(res[idx], want_res))}
+        if world == 1 and not args.no_cpu_baseline:
+            fr_all = d_frames.cpu().numpy()
+            done, t_cpu = 0, 0.0
+            chunk = 250
+            while t_cpu < args.cpu_seconds:
+                lo = done % n
+                c0 = time.perf_counter()
+                O.mdec_encode(args.codec, w, h, fr_all[lo:lo + chunk], budget)
+                t_cpu += time.perf_counter() - c0
+                done += min(chunk, n - lo)
+            cpu_baseline = {"value": round(done / t_cpu, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": "%d frames of the same workload (oracle/mdec_oracle.c, gcc -O3, %d host cores present)" % (done, os.cpu_count() or 0)}
+
+    total_frames = n * world * args.steps
+    value = total_frames / elapsed
+    alg_bytes = (w * h * 3 // 2 + budget) * n            # per launch: NV21 read + frame_max_size written, per frame
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    scales, counts = np.unique(res[:, 0], return_counts=True)
+
+    if rank == 0:
+        line = {
+            "metric": "bs_v2_320x240_frames_per_sec" if (args.codec == 0 and w == 320 and h == 240) else "bs_frames_per_sec",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "sbs v2: %d synthetic %dx%d NV21 frames per GPU per step, frame_max_size %d, codec %s, noise +-%d"
+                                   % (n, w, h, budget, ["v2", "v3", "v3dc"][args.codec], args.amp),
+                       "frames_per_gpu": n, "width": w, "height": h, "frame_max_size": budget,
+                       "parallelism": "frames sharded x%d, no data-path collective" % world,
+                       "quant_scale_hist": {str(int(s)): int(c) for s, c in zip(scales, counts)}},
+            "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu_baseline,
+            "parity": parity,
+            "results_sane": ok_local,
+        }
+        print(json.dumps(line), flush=True)
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

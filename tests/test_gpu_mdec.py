@@ -1,0 +1,209 @@
+"""GPU parity tests of the MDEC BS frame encoder: libpsxav_hip.so (through its C ABI) vs the CPU oracle on the
+same seeded inputs, vs the committed vectors, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Bar: bit-exact (integer path)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mdec_selfgolden.npz")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def encoder(codec, w, h, budget):
+    from psxavenc_amd.mdec import MdecEncoder
+    return MdecEncoder(codec, w, h, max_frame_size=budget, device=0)
+
+
+def assert_same(got, got_res, want, want_res, tag=""):
+    assert np.array_equal(got_res, want_res), (tag, got_res[:4], want_res[:4])
+    if not np.array_equal(got, want):
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        k = int(bad[0])
+        at = int(np.nonzero(got[k] != want[k])[0][0])
+        raise AssertionError("%s: %d frames differ; frame %d first differs at byte %d" % (tag, bad.size, k, at))
+
+
+def test_library_is_the_hip_build():
+    from psxavenc_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    assert b"gfx950" in _lib.lib().psxhip_version()
+
+
+def test_selfgolden_matrix_all_cases():
+    """every (codec, size, budget, content) case of the committed matrix, against hashes AND the live oracle"""
+    g = np.load(GOLD)
+    from psxavenc_amd import _lib
+    for row in g["table"]:
+        codec, w, h, budget, amp, n, rc = (int(v) for v in row[:7])
+        fr = O.synth_frames(w, h, n, seed=100 + amp, amp=amp, first=3)
+        enc = encoder(codec, w, h, budget)
+        if rc != 0:
+            with pytest.raises(_lib.PsxHipError) as e:
+                enc.encode_frames_host(fr, budget)
+            assert e.value.code == _lib.PSXHIP_ENOFIT
+        else:
+            out, res = enc.encode_frames_host(fr, budget)
+            assert res.ravel().tolist() == row[7:7 + 4 * n].tolist(), row[:7]
+            assert hashlib.sha256(out.tobytes()).digest() == g["sha_c%d_%dx%d_b%d_a%d" % (codec, w, h, budget, amp)].tobytes(), row[:7]
+        enc.close()
+
+
+def test_special_frames_vs_oracle():
+    """flat fields (v3 DC ties in both directions), 8x8 checkerboard (DC deltas near +-255, v3dc wrap),
+    hard edges (escape codes), DC staircase"""
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tests", "golden"))
+    from make_mdec_golden import special_frames
+    g = np.load(GOLD)
+    from psxavenc_amd import _lib
+    for codec in (0, 1, 2):
+        for (w, h, budget) in ((48, 32, 4096), (320, 240, 30000), (320, 240, 9000)):
+            fr = special_frames(w, h)
+            enc = encoder(codec, w, h, budget)
+            key = "special_c%d_%dx%d_b%d" % (codec, w, h, budget)
+            for k in range(fr.shape[0]):
+                want, want_res, rc = O.mdec_encode(codec, w, h, fr[k:k + 1], budget)
+                assert rc == int(g[key + "_rc"][k])
+                if rc == 0:
+                    out, res = enc.encode_frames_host(fr[k:k + 1], budget)
+                    assert_same(out, res, want, want_res, "%s frame %d" % (key, k))
+                    assert hashlib.sha256(out.tobytes()).digest() == g[key + "_sha"][k].tobytes()
+                else:
+                    with pytest.raises(_lib.PsxHipError):
+                        enc.encode_frames_host(fr[k:k + 1], budget)
+            enc.close()
+
+
+def test_escape_codes_are_exercised():
+    """the hard-edge frame must actually contain 22-bit escapes at its accepted scale (guards the test above)"""
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tests", "golden"))
+    from make_mdec_golden import special_frames
+    fr = special_frames(320, 240)[8:9]
+    out, res, rc = O.mdec_encode(0, 320, 240, fr, 30000)
+    assert rc == 0
+    _, levels, scale, _, _ = O.mdec_decode(320, 240, out[0])
+    assert (np.abs(levels[:, 1:]) > 40).any()
+
+
+@pytest.mark.parametrize("codec", [0, 1, 2])
+def test_per_frame_budgets_str_cycle(codec):
+    """strcd config: budgets cycle 16128, 18144, 18144, 18144, odd budgets mixed in"""
+    w, h, n = 320, 240, 24
+    fr = O.synth_frames(w, h, n, seed=42, amp=8)
+    budgets = np.array([16128, 18144, 18144, 18144] * (n // 4), np.int32)
+    budgets[5] = 8191
+    budgets[6] = 4097
+    want, want_res, rc = O.mdec_encode(codec, w, h, fr, budgets, stride=18144)
+    assert rc == 0
+    enc = encoder(codec, w, h, 18144)
+    out, res = enc.encode_frames_host(fr, budgets)
+    assert_same(out, res, want, want_res, "str cycle")
+    enc.close()
+
+
+def test_device_path_equals_host_path_and_is_stream_ordered(torch_cuda):
+    torch = torch_cuda
+    w, h, n, budget = 320, 240, 40, 8192
+    fr = O.synth_frames(w, h, n, seed=5, amp=4)
+    enc = encoder(0, w, h, budget)
+    host_out, host_res = enc.encode_frames_host(fr, budget)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = torch.from_numpy(fr).to("cuda:0", non_blocking=False)
+        d_out, d_res = enc.encode_frames_device(d, budget)
+        d_out2, d_res2 = enc.encode_frames_device(d, budget)     # back-to-back launches share the scratch slab
+    s.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), host_out) and np.array_equal(d_res.cpu().numpy(), host_res)
+    assert np.array_equal(d_out2.cpu().numpy(), host_out)
+    enc.close()
+
+
+def test_drop_in_single_frame_call_pattern():
+    """encode_file_sbs's loop (filefmt.c:633-662): frame_max_size poked by the caller, one frame per call,
+    quant_scale_sum accumulated across calls"""
+    w, h, budget = 320, 240, 8192
+    fr = O.synth_frames(w, h, 5, seed=77, amp=8)
+    want, want_res, _ = O.mdec_encode(0, w, h, fr, budget)
+    enc = encoder(0, w, h, budget)
+    enc.frame_max_size = budget
+    for k in range(5):
+        out = enc.encode_frame_bs(fr[k])
+        assert np.array_equal(out, want[k])
+        assert [enc.quant_scale, enc.bytes_used, enc.blocks_used, enc.uncomp_hwords_used] == want_res[k].tolist()
+    assert enc.quant_scale_sum == int(want_res[:, 0].sum())
+    enc.close()
+
+
+def test_full_size_sbs_v2_1000_frames(torch_cuda):
+    """BASELINE config 'sbs v2': 1000 synthetic 320x240 frames, budget 8192 -- every byte against the oracle,
+    with more frames than resident workgroups (persistent loop) and both content classes."""
+    torch = torch_cuda
+    from psxavenc_amd import synth
+    w, h, n, budget = 320, 240, 1000, 8192
+    enc = encoder(0, w, h, budget)
+    for amp in (4, 8):
+        d_frames = synth.frames_device(w, h, seed=1, first=0, n=n, amp=amp, device=0)
+        d_out, d_res = enc.encode_frames_device(d_frames, budget)
+        torch.cuda.synchronize()
+        fr = d_frames.cpu().numpy()
+        assert np.array_equal(fr[:3], O.synth_frames(w, h, 3, seed=1, amp=amp))
+        want, want_res, rc = O.mdec_encode(0, w, h, fr, budget)
+        assert rc == 0
+        assert_same(d_out.cpu().numpy()[:, :budget], d_res.cpu().numpy(), want, want_res, "sbs v2 amp %d" % amp)
+    enc.close()
+
+
+def test_full_size_sbs_v3_640x480_properties(torch_cuda):
+    """BASELINE config 'sbs v3' shape (640x480, one GPU's share): oracle on a sample, and size-independent
+    properties on everything: header fields, zero tail, decodability, bits consistent with bytes_used."""
+    torch = torch_cuda
+    from psxavenc_amd import synth
+    w, h, n, budget = 640, 480, 320, 32768
+    enc = encoder(1, w, h, budget)
+    d_frames = synth.frames_device(w, h, seed=2, first=5000, n=n, amp=8, device=0)
+    d_out, d_res = enc.encode_frames_device(d_frames, budget)
+    torch.cuda.synchronize()
+    out, res = d_out.cpu().numpy(), d_res.cpu().numpy()
+    assert ((res[:, 0] >= 1) & (res[:, 0] <= 63)).all()
+    assert (out[:, 2] == 0).all() and (out[:, 3] == 0x38).all() and (out[:, 6] == 3).all() and (out[:, 7] == 0).all()
+    assert np.array_equal(out[:, 4].astype(np.int32) | (out[:, 5].astype(np.int32) << 8), res[:, 0])
+    assert np.array_equal(out[:, 0].astype(np.int32) | (out[:, 1].astype(np.int32) << 8), res[:, 2])
+    for k in range(n):
+        assert not out[k, res[k, 1]:].any()
+    idx = list(range(0, n, 16))
+    fr = d_frames[idx].cpu().numpy()
+    want, want_res, rc = O.mdec_encode(1, w, h, fr, budget)
+    assert rc == 0
+    assert_same(out[idx][:, :budget], res[idx], want, want_res, "sbs v3 sample")
+    for k in idx[:4]:
+        rc2, levels, scale, version, nbits = O.mdec_decode(w, h, out[k])
+        assert rc2 == 0 and version == 3 and scale == res[k, 0]
+        assert res[k, 1] == ((8 + 2 * ((nbits + 15) // 16) + 3) & ~3)
+        assert res[k, 3] == ((int(np.count_nonzero(levels[:, 1:])) + 2 * levels.shape[0] + 2 + 63) & ~63)
+    enc.close()
+
+
+def test_bad_arguments_fail_loudly():
+    from psxavenc_amd import _lib
+    from psxavenc_amd.mdec import MdecEncoder
+    with pytest.raises(_lib.PsxHipError):
+        MdecEncoder(0, 321, 240)
+    with pytest.raises(_lib.PsxHipError):
+        MdecEncoder(3, 320, 240)
+    enc = MdecEncoder(0, 320, 240, max_frame_size=8192)
+    with pytest.raises(_lib.PsxHipError):
+        enc.encode_frames_host(np.zeros((1, 320 * 240 * 3 // 2), np.uint8), 9000)     # above the context's maximum
+    enc.close()

@@ -1,0 +1,158 @@
+"""CPU-side checks of the MDEC restatement (oracle/mdec_oracle.c): FDCT sanity pins, the closed
+forms the HIP kernel relies on (integer rounding division, fp32 reciprocal quantiser, first-fit rate control),
+self-golden regression vectors and encode -> decode round trips."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import scipy.fft
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mdec_selfgolden.npz")
+
+
+def fdct(block):
+    b = np.ascontiguousarray(block, dtype=np.int16).copy()
+    O.lib().orc_fdct_islow8(O.ptr(b, O.i16p))
+    return b
+
+
+def test_fdct_constant_blocks():
+    for c in (-128, -1, 0, 1, 5, 127):
+        out = fdct(np.full(64, c))
+        assert out[0] == 64 * c and not out[1:].any()
+
+
+def test_fdct_close_to_float_dct():
+    rng = np.random.default_rng(5)
+    blocks = [rng.integers(-128, 128, 64) for _ in range(500)]
+    yy, xx = np.mgrid[0:8, 0:8]
+    blocks += [((xx + yy) * 16 - 112).ravel(), (((xx + yy) & 1) * 255 - 128).ravel(), (((xx // 4) & 1) * 255 - 128).ravel()]
+    worst = 0.0
+    for b in blocks:
+        want = 8.0 * scipy.fft.dctn(np.asarray(b, float).reshape(8, 8), norm="ortho")
+        worst = max(worst, np.abs(fdct(b).reshape(8, 8) - want).max())
+    assert worst < 1.0
+
+
+def test_dc_range_matches_clamp_range():
+    # DC = round(64*c/16): c=127 -> 508, c=-128 -> -512 (the clamp range at mdec.c:262-265)
+    assert fdct(np.full(64, 127))[0] == 8128 and round(8128 / 16) == 508
+    assert fdct(np.full(64, -128))[0] == -8192 and round(-8192 / 16) == -512
+
+
+def test_integer_form_of_divide_rounded():
+    """mdec.c:438 (round-half-away of n/d in double) == sgn(n) * ((2|n| + d) // (2d)) for every divisor in use."""
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tools"))
+    import gen_tables as G
+    divisors = sorted({q * s for q in G.QUANT[1:] for s in range(1, 64)} | {16, 4})
+    n = np.arange(-40000, 40001, dtype=np.int64)
+    for d in divisors[::7] + [16, 4]:
+        x = n / float(d)
+        ref = np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5)).astype(np.int64)   # round half away from zero
+        mine = np.sign(n) * ((2 * np.abs(n) + d) // (2 * d))
+        assert np.array_equal(ref, mine), d
+
+
+def test_fp32_reciprocal_quantiser_is_exact():
+    """The kernel computes floor(N / D) as trunc((float(N) + 0.5f) * rcp(D)), N = 2|n| + d, D = 2d.
+    Exhaustive over every divisor and every N the path can produce, with the reciprocal perturbed by +-2 ulp
+    (v_rcp_f32 is 1 ulp)."""
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tools"))
+    import gen_tables as G
+    divisors = sorted({q * s for q in G.QUANT[1:] for s in range(1, 65)})
+    a2 = 2 * np.arange(0, 32769, dtype=np.int64)
+    for d in divisors:
+        N = a2 + d
+        D = 2 * d
+        want = N // D
+        r = np.float32(1.0) / np.float32(D)
+        for ulps in (-2, 0, 2):
+            rr = r
+            for _ in range(abs(ulps)):
+                rr = np.nextafter(rr, np.float32(np.inf if ulps > 0 else -np.inf), dtype=np.float32)
+            got = ((N.astype(np.float32) + np.float32(0.5)) * rr).astype(np.int64)
+            assert np.array_equal(got, want), (d, ulps)
+
+
+def _levels_numpy(coefs, scale):
+    """Quantised levels [6, nmb, 64] (raster order) by the integer closed form."""
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tools"))
+    import gen_tables as G
+    q = np.array(G.QUANT, np.int64) * scale
+    q[0] = 16
+    n = coefs.astype(np.int64)
+    lv = np.sign(n) * ((2 * np.abs(n) + q) // (2 * q))
+    return np.clip(lv, -512, 510)
+
+
+@pytest.mark.parametrize("codec,w,h,budget,amp", [(0, 320, 240, 8192, 4), (1, 320, 240, 8192, 8), (2, 48, 32, 4096, 8),
+                                                   (1, 640, 480, 32768, 8), (0, 16, 16, 4096, 0)])
+def test_roundtrip_decode_recovers_levels(codec, w, h, budget, amp):
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "tools"))
+    import gen_tables as G
+    fr = O.synth_frames(w, h, 2, seed=9, amp=amp)
+    out, res, rc = O.mdec_encode(codec, w, h, fr, budget)
+    assert rc == 0
+    nx, ny = w // 16, h // 16
+    zz = np.array(G.zagzig())
+    for k in range(2):
+        rc2, levels, scale, version, nbits = O.mdec_decode(w, h, out[k], v3dc_wrap=int(codec == 2))
+        assert rc2 == 0 and scale == res[k, 0] and version == (2 if codec == 0 else 3)
+        assert res[k, 1] == ((8 + 2 * ((nbits + 15) // 16) + 3) & ~3)
+        want = _levels_numpy(O.mdec_coefs(w, h, fr[k]), scale)           # [6, nmb, 64] raster, mb index fy*nx+fx
+        # decoder order: macroblocks fx-major, 6 blocks each, zig-zag inside
+        got = levels.reshape(nx, ny, 6, 64)
+        for fx in range(nx):
+            for fy in range(ny):
+                w_ = want[:, fy * nx + fx, :][:, zz]
+                assert np.array_equal(got[fx, fy][:, 1:], w_[:, 1:]), (fx, fy)
+                if codec == 0:
+                    assert np.array_equal(got[fx, fy][:, 0], w_[:, 0])
+                else:   # v3 carries DC as a DPCM of multiples of 4 (mdec.c:460-461): decoder sees dc rounded to 4
+                    assert not (got[fx, fy][:, 0] & 3).any()
+                    assert np.abs(got[fx, fy][:, 0].astype(int) - w_[:, 0]).max() <= 2
+        # everything after the end-of-frame code is zero (the reference's memset, mdec.c:676)
+        assert not out[k, res[k, 1]:].any()
+        rec = O.mdec_reconstruct(w, h, levels, scale)
+        mse = ((rec.astype(float) - fr[k]) ** 2).mean()
+        assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-9)) > 30.0
+
+
+def test_rate_control_is_first_fit():
+    """chosen scale = min s with 8 + 2*ceil(bits(s)/16) <= budget; one step tighter budget moves to a later scale."""
+    w, h = 320, 240
+    fr = O.synth_frames(w, h, 1, seed=3, amp=8)
+    out, res, rc = O.mdec_encode(0, w, h, fr, 60000)
+    assert rc == 0 and res[0, 0] == 1
+    _, _, _, _, nbits = O.mdec_decode(w, h, out[0])
+    need = 8 + 2 * ((nbits + 15) // 16)
+    for budget, expect_scale1 in ((need, True), (need + 1, True), (need - 1, False), (need - 2, False)):
+        _, r2, rc2 = O.mdec_encode(0, w, h, fr, budget)
+        assert rc2 == 0 and (r2[0, 0] == 1) == expect_scale1, (budget, r2)
+
+
+def test_no_fit_is_reported():
+    fr = O.synth_frames(320, 240, 1, seed=3, amp=8)
+    _, _, rc = O.mdec_encode(0, 320, 240, fr, 2700)       # floor: 1800*12+10 bits = 2710 bytes of payload
+    assert rc == -2
+
+
+def test_selfgolden_vectors():
+    g = np.load(GOLD)
+    t = g["table"]
+    for row in t[::3]:                                    # every third case keeps the CPU suite quick; the GPU suite runs all
+        codec, w, h, budget, amp, n, rc = (int(v) for v in row[:7])
+        fr = O.synth_frames(w, h, n, seed=100 + amp, amp=amp, first=3)
+        out, res, rc2 = O.mdec_encode(codec, w, h, fr, budget)
+        assert rc2 == rc
+        if rc == 0:
+            assert res.ravel().tolist() == row[7:7 + 4 * n].tolist()
+            sha = hashlib.sha256(out.tobytes()).digest()
+            assert sha == g["sha_c%d_%dx%d_b%d_a%d" % (codec, w, h, budget, amp)].tobytes()
