@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite result (kernel-trace stats and PMC counters) as text.
+usage: rocpd_summary.py <results.db> [...]"""
+import sqlite3
+import sys
+
+
+def summarise(path):
+    c = sqlite3.connect(path)
+    print("== %s" % path)
+    try:
+        rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                         "from kernels group by name order by 3 desc").fetchall()
+        tot = sum(r[2] for r in rows) or 1
+        print("%-64s %8s %14s %14s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"))
+        for r in rows:
+            print("%-64s %8d %14d %14.1f %12d %12d %6.2f%%" % (r[0][:64], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot))
+    except sqlite3.Error as e:
+        print("no kernel table:", e)
+    try:
+        cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+        if cols:
+            rows = c.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                             "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+            if rows:
+                print("%-48s %-24s %8s %18s" % ("kernel", "counter", "samples", "avg per dispatch"))
+                for r in rows:
+                    print("%-48s %-24s %8d %18.1f" % (r[0][:48], r[1], r[2], r[3]))
+    except sqlite3.Error as e:
+        print("no counters:", e)
+
+
+for p in sys.argv[1:]:
+    summarise(p)
