@@ -82,38 +82,53 @@ typedef struct {
 } psxhip_adpcm_state_t;
 
 /* One independent encoder chain: `n_units` consecutive 28-sample sound units read from
- * d_samples + sample_offset with stride `pitch` (int16 elements); samples at index >= sample_limit
- * (counted in units of `pitch`, like adpcm.c:65,110) read as zero. */
+ * d_samples + sample_offset with stride `pitch` (int16 elements); chain-local samples at index
+ * >= sample_limit read as zero without touching memory (what the reference gets from its zero-padded
+ * input, adpcm.c:65,110 and decoding.c:497-503).  Unit u of the chain is written to record
+ * unit_base[c] + u * unit_stride, so the L/R chains of a stereo XA stream interleave into encode order. */
 typedef struct {
 	int64_t sample_offset;   /* element offset into d_samples */
 	int32_t pitch;           /* 1 = mono / planar, 2 = interleaved stereo */
-	int32_t sample_limit;    /* valid samples in this chain from sample_offset on */
+	int32_t sample_limit;    /* valid samples of this chain from sample_offset on */
 	int32_t n_units;         /* sound units to encode */
-	int32_t reserved;
+	int32_t unit_stride;     /* record stride, normally 1 (2 for the halves of a stereo pair) */
 } psxhip_adpcm_chain_t;
 
-/* Encode n_chains independent chains.  filter_count 5 (SPU) or 4 (XA); bits 4 or 8
- * (shift range 12 / 8, adpcm.c:29-34).  Output per unit: 1 header byte
- * ((shift & 15) | filter << 4) followed by 28 code bytes (masked to `bits` bits), i.e. 29-byte
- * records at d_units + (unit_base[c] + u) * 32 (32-byte stride).  d_states[c] is read and updated. */
-int psxhip_adpcm_encode_chains_device(int device, const int16_t *d_samples, const psxhip_adpcm_chain_t *d_chains,
-                                      const int32_t *d_unit_base, int n_chains, int max_units, int filter_count,
-                                      int bits, psxhip_adpcm_state_t *d_states, uint8_t *d_units, void *stream);
+#define PSXHIP_ADPCM_RECORD_BYTES 32   /* byte 0: (shift & 15) | filter << 4; bytes 4..31: the 28 codes */
 
-/* Pack unit records into 16-byte SPU blocks (adpcm.c:367-372): n_blocks records -> d_out. */
+/* Encode n_chains independent chains.  filter_count 5 (SPU) or 4 (XA); bits 4 or 8 (shift range
+ * 12 / 8, adpcm.c:29-34).  Output: one 32-byte record per unit (see above) in d_units; d_states[c]
+ * is read and updated.  Result per unit == libpsxav/adpcm.c:142-191 encode(). */
+int psxhip_adpcm_encode_chains_device(int device, const int16_t *d_samples, const psxhip_adpcm_chain_t *d_chains,
+                                      const int32_t *d_unit_base, int n_chains, int filter_count, int bits,
+                                      psxhip_adpcm_state_t *d_states, uint8_t *d_units, void *stream);
+
+/* Pack n_blocks unit records into 16-byte SPU blocks (adpcm.c:367-372).  d_out 16-byte aligned. */
 int psxhip_spu_pack_device(int device, const uint8_t *d_units, int n_blocks, uint8_t *d_out, void *stream);
 
-/* Assemble XA sectors from unit records (adpcm.c:193-233,266-332): sector s of the stream takes its
- * 18 groups x (8 | 4) units from records [s*units_per_sector ...), laid out in encode order.
- * Writes sector_size bytes per sector (2336 .xa / 2352 XACD) incl. sync, BCD time code, subheaders
- * and the form-2 EDC (libpsxav/cdrom.c:28-41,55-74,102-110). */
+/* Assemble XA sectors from unit records in encode order (adpcm.c:193-233,266-332): sector s takes
+ * records [s * 18 * U, (s+1) * 18 * U), U = 8 (4-bit) or 4 (8-bit) units per sound group.  Writes
+ * 2336 (.xa, format 0) or 2352 (XACD, format 1) bytes per sector incl. sync, BCD time code,
+ * subheaders and the form-2 EDC (libpsxav/cdrom.c:28-41,55-74,102-110); bytes the reference leaves
+ * unwritten are zero.  d_eof_flags (optional): non-zero entries set the EOF submode bit
+ * (psx_audio_xa_encode_finalize, adpcm.c:334-340). */
 int psxhip_xa_assemble_device(int device, const uint8_t *d_units, int n_sectors, int format, int stereo,
                               int frequency, int bits, int file_number, int channel_number, int first_lba,
-                              uint8_t *d_out, void *stream);
+                              const uint8_t *d_eof_flags, uint8_t *d_out, void *stream);
 
-/* Host-buffer convenience: n_streams independent SPU streams of equal length. */
-int psxhip_spu_encode_streams_host(int device, const int16_t *samples, int n_streams, int samples_per_stream,
-                                   psxhip_adpcm_state_t *states, uint8_t *out);
+/* Host-buffer batches.  n_streams independent streams, stream i at samples + i*stream_stride
+ * (elements), samples_per_stream samples each read with `pitch`; states[i] is carried in and out.
+ * SPU: stream i's 16 * ceil(n/28) bytes go to out + i*out_stride.  Returns bytes per stream or < 0. */
+int psxhip_spu_encode_streams_host(int device, const int16_t *samples, int n_streams, int64_t stream_stride,
+                                   int pitch, int samples_per_stream, psxhip_adpcm_state_t *states,
+                                   uint8_t *out, int64_t out_stride);
+/* XA: stereo streams are interleaved L,R (samples_per_stream counts per channel); states[2*i] /
+ * states[2*i+1] are the left / right channel states; lbas[i] is the first sector's LBA.  finalize != 0
+ * sets EOF on each stream's last sector.  Returns bytes per stream (whole sectors) or < 0. */
+int psxhip_xa_encode_streams_host(int device, int format, int stereo, int frequency, int bits, int file_number,
+                                  int channel_number, const int16_t *samples, int n_streams, int64_t stream_stride,
+                                  int samples_per_stream, const int32_t *lbas, psxhip_adpcm_state_t *states,
+                                  uint8_t *out, int64_t out_stride, int finalize);
 
 /* ---------------------------------------------------------------- synthetic inputs --------- */
 

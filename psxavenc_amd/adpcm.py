@@ -1,0 +1,172 @@
+"""SPU / XA ADPCM encoder -- Python mirror of include/psxav_audio.h / psxav_hip.h.
+
+Reference surface: ``psx_audio_spu_encode``, ``psx_audio_xa_encode`` (+ ``_simple``, ``_finalize`` and the
+size helpers), libpsxav/libpsxav.h:73-101.  State objects carry ``prev1 / prev2`` exactly like
+``psx_audio_encoder_channel_state_t`` so calls can be chained (28 samples per call for ``-t spu``, one
+sector per call for xa/str, filefmt.c:184,243).  Batched forms encode many independent streams per launch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PSX_AUDIO_XA_FORMAT_XA, PSX_AUDIO_XA_FORMAT_XACD = 0, 1           # libpsxav.h:39-42
+PSX_AUDIO_XA_FREQ_SINGLE, PSX_AUDIO_XA_FREQ_DOUBLE = 18900, 37800  # libpsxav.h:34-37
+PSX_AUDIO_SPU_BLOCK_SIZE, PSX_AUDIO_SPU_SAMPLES_PER_BLOCK = 16, 28
+PSX_AUDIO_SPU_LOOP_END, PSX_AUDIO_SPU_LOOP_REPEAT, PSX_AUDIO_SPU_LOOP_START, PSX_AUDIO_SPU_LOOP_TRAP = 1, 3, 6, 5
+RECORD_BYTES = 32
+
+
+def _bind():
+    L = _lib.lib()
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.psxhip_spu_encode_streams_host.argtypes = [i32, vp, i32, i64, i32, i32, vp, vp, i64]
+    L.psxhip_xa_encode_streams_host.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, i32, i64, i32, vp, vp, vp, i64, i32]
+    L.psxhip_adpcm_encode_chains_device.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.psxhip_spu_pack_device.argtypes = [i32, vp, i32, vp, vp]
+    L.psxhip_xa_assemble_device.argtypes = [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    return L
+
+
+class XaSettings:
+    """psx_audio_xa_settings_t (libpsxav.h:44-51)"""
+
+    def __init__(self, format=PSX_AUDIO_XA_FORMAT_XA, stereo=True, frequency=37800, bits_per_sample=4, file_number=0,
+                 channel_number=0):
+        self.format, self.stereo, self.frequency = int(format), bool(stereo), int(frequency)
+        self.bits_per_sample, self.file_number, self.channel_number = int(bits_per_sample), int(file_number), int(channel_number)
+
+
+# ---- size helpers (adpcm.c:235-260): pure arithmetic, kept in Python for the mirror ---------------
+def xa_get_buffer_size_per_sector(s):
+    return 2336 if s.format == PSX_AUDIO_XA_FORMAT_XA else 2352
+
+
+def xa_get_samples_per_sector(s):
+    return ((112 if s.bits_per_sample == 8 else 224) >> (1 if s.stereo else 0)) * 18
+
+
+def xa_get_sector_interleave(s):
+    v = 2 if s.stereo else 4
+    if s.frequency == PSX_AUDIO_XA_FREQ_SINGLE:
+        v <<= 1
+    if s.bits_per_sample == 4:
+        v <<= 1
+    return v
+
+
+def xa_get_buffer_size(s, sample_count):
+    sps = xa_get_samples_per_sector(s)
+    return ((sample_count + sps - 1) // sps) * xa_get_buffer_size_per_sector(s)
+
+
+def spu_get_buffer_size(sample_count):
+    return ((sample_count + 27) // 28) << 4
+
+
+# ---- batched host paths -------------------------------------------------------------------------
+def spu_encode_streams(samples, pitch=1, states=None, sample_count=None, device=0):
+    """samples: int16 (n_streams, >= sample_count*pitch).  Returns (n_streams, 16*ceil(n/28)) uint8;
+    `states` (n_streams, 2) int32 [prev1, prev2] is updated in place when given."""
+    L = _bind()
+    samples = np.ascontiguousarray(samples, dtype=np.int16)
+    assert samples.ndim == 2
+    n_streams = samples.shape[0]
+    n = samples.shape[1] // pitch if sample_count is None else sample_count
+    st = np.zeros((n_streams, 2), np.int32) if states is None else states
+    assert st.dtype == np.int32 and st.shape == (n_streams, 2) and st.flags.c_contiguous
+    out = np.zeros((n_streams, spu_get_buffer_size(n)), np.uint8)
+    rc = L.psxhip_spu_encode_streams_host(device, samples.ctypes.data, n_streams, samples.shape[1], pitch, n, st.ctypes.data,
+                                          out.ctypes.data, out.shape[1])
+    if rc < 0:
+        _lib.check(rc)
+    return out
+
+
+def xa_encode_streams(settings, samples, sample_count, lbas=None, states=None, finalize=False, device=0):
+    """samples: int16 (n_streams, >= sample_count * channels), interleaved L,R when stereo.
+    Returns (n_streams, sectors*sector_size) uint8.  states: (n_streams, 2, 2) int32 [[l1,l2],[r1,r2]]."""
+    L = _bind()
+    samples = np.ascontiguousarray(samples, dtype=np.int16)
+    n_streams = samples.shape[0]
+    ch = 2 if settings.stereo else 1
+    assert samples.shape[1] >= sample_count * ch
+    st = np.zeros((n_streams, 2, 2), np.int32) if states is None else states
+    assert st.dtype == np.int32 and st.shape == (n_streams, 2, 2) and st.flags.c_contiguous
+    st_dev = np.ascontiguousarray(st[:, :ch, :].reshape(n_streams * ch, 2))
+    lb = np.zeros(n_streams, np.int32) if lbas is None else np.ascontiguousarray(lbas, dtype=np.int32)
+    upg = 8 if settings.bits_per_sample == 4 else 4
+    groups = (sample_count * ch + upg * 28 - 1) // (upg * 28)
+    sectors = (groups + 17) // 18
+    size = sectors * xa_get_buffer_size_per_sector(settings)
+    out = np.zeros((n_streams, max(size, 1)), np.uint8)
+    rc = L.psxhip_xa_encode_streams_host(device, settings.format, int(settings.stereo), settings.frequency,
+                                         settings.bits_per_sample, settings.file_number, settings.channel_number,
+                                         samples.ctypes.data, n_streams, samples.shape[1], sample_count, lb.ctypes.data,
+                                         st_dev.ctypes.data, out.ctypes.data, out.shape[1], int(bool(finalize)))
+    if rc < 0:
+        _lib.check(rc)
+    st[:, :ch, :] = st_dev.reshape(n_streams, ch, 2)
+    return out[:, :size]
+
+
+# ---- reference-shaped single-stream calls ---------------------------------------------------------
+class ChannelState:
+    """psx_audio_encoder_channel_state_t (libpsxav.h:53-57); qerr/mse are dead fields in the reference."""
+
+    def __init__(self):
+        self.prev1 = 0
+        self.prev2 = 0
+
+
+class EncoderState:
+    """psx_audio_encoder_state_t (libpsxav.h:59-62)"""
+
+    def __init__(self):
+        self.left, self.right = ChannelState(), ChannelState()
+
+
+def psx_audio_spu_encode(state, samples, sample_count, pitch=1, device=0):
+    st = np.array([[state.prev1, state.prev2]], np.int32)
+    samples = np.asarray(samples, dtype=np.int16).reshape(1, -1)
+    out = spu_encode_streams(samples, pitch=pitch, states=st, sample_count=sample_count, device=device)
+    state.prev1, state.prev2 = int(st[0, 0]), int(st[0, 1])
+    return out[0]
+
+
+def psx_audio_spu_encode_simple(samples, sample_count, loop_start, device=0):
+    """adpcm.c:378-401: zero state, then the trailing LOOP_TRAP block or the loop flags."""
+    out = psx_audio_spu_encode(ChannelState(), samples, sample_count, 1, device=device)
+    if out.size >= 16:
+        if loop_start < 0:
+            trap = np.zeros(16, np.uint8)
+            trap[1] = PSX_AUDIO_SPU_LOOP_TRAP
+            out = np.concatenate([out, trap])
+        else:
+            out[out.size - 16 + 1] |= PSX_AUDIO_SPU_LOOP_REPEAT
+            out[loop_start // 28 * 16 + 1] |= PSX_AUDIO_SPU_LOOP_START
+    return out
+
+
+def psx_audio_xa_encode(settings, state, samples, sample_count, lba, device=0):
+    st = np.array([[[state.left.prev1, state.left.prev2], [state.right.prev1, state.right.prev2]]], np.int32)
+    samples = np.asarray(samples, dtype=np.int16).reshape(1, -1)
+    out = xa_encode_streams(settings, samples, sample_count, lbas=[lba], states=st, device=device)
+    state.left.prev1, state.left.prev2 = int(st[0, 0, 0]), int(st[0, 0, 1])
+    state.right.prev1, state.right.prev2 = int(st[0, 1, 0]), int(st[0, 1, 1])
+    return out[0]
+
+
+def psx_audio_xa_encode_finalize(settings, output):
+    """adpcm.c:334-340: OR the EOF bit into the last sector's submode (both subheader copies)."""
+    if output.size >= 2336:
+        base = output.size - 2352      # may be -16 for a single .xa sector: only offsets >= 16 are touched
+        output[base + 18] |= 0x80
+        output[base + 20:base + 24] = output[base + 16:base + 20]
+    return output
+
+
+def psx_audio_xa_encode_simple(settings, samples, sample_count, lba, device=0):
+    out = psx_audio_xa_encode(settings, EncoderState(), samples, sample_count, lba, device=device)
+    return psx_audio_xa_encode_finalize(settings, out)

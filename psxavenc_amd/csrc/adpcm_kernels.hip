@@ -1,0 +1,408 @@
+// adpcm_kernels.hip -- SPU / XA ADPCM filter x shift search for MI355X (gfx950), hand-written HIP.
+//
+// Replaces libpsxav/adpcm.c:39-191 (find_min_shift, attempt_to_encode, encode) for batches of
+// independent encoder chains, plus the SPU block packing (adpcm.c:367-372) and the XA sound-group /
+// sector assembly with its EDC (adpcm.c:193-233,266-332; cdrom.c:28-41,55-74,102-110).
+//
+// A chain (one SPU stream, or one XA channel side) is serial in time: the two last DECODED samples
+// feed the next sound unit (adpcm.c:135-136).  Inside one unit the reference tries, for each of the
+// 4 (XA) or 5 (SPU) filters, the <=3 shifts around that filter's minimum shift and keeps the first
+// strict minimum of the squared error in (filter, shift) loop order (adpcm.c:158-183).  Mapping:
+//   * 16 lanes per chain = one DPP row; lane c of the row owns candidate (filter c/3, shift m-1+c%3);
+//     4 chains per wavefront;
+//   * every lane runs the 28-step predictor recursion for its own candidate in registers;
+//   * the winner is a 16-lane DPP min-reduce on the packed key (sse << 8 | filter << 4 | shift),
+//     which orders candidates exactly like the reference's loop + strict '<';
+//   * the winning lane stores the unit's record and its decoded state is broadcast to the row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "psxhip_internal.h"
+
+namespace {
+
+constexpr int kRecordBytes = 32;   // [0] header, [4..31] 28 codes
+
+__device__ __forceinline__ int predict(int k1, int k2, int p1, int p2) { return (k1 * p1 + k2 * p2 + 32) >> 6; }
+
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// minimum over each 16-lane row, result in every lane of the row (row_ror:8,4,2,1)
+__device__ __forceinline__ uint64_t row_min_u64(uint64_t v) {
+    uint64_t o;
+    o = dpp64<0x128>(v); v = o < v ? o : v;
+    o = dpp64<0x124>(v); v = o < v ? o : v;
+    o = dpp64<0x122>(v); v = o < v ? o : v;
+    o = dpp64<0x121>(v); v = o < v ? o : v;
+    return v;
+}
+
+struct ChainJob {
+    const int16_t* samples;
+    const psxhip_adpcm_chain_t* chains;
+    const int32_t* unit_base;
+    int n_chains;
+    int filter_count;   // 5 SPU, 4 XA
+    int range;          // 12 (4-bit) or 8 (8-bit)
+    psxhip_adpcm_state_t* states;
+    uint8_t* units;
+};
+
+__global__ __launch_bounds__(64) void adpcm_chains_kernel(const ChainJob job) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int cand = lane & 15;
+    const int chain = (int)blockIdx.x * 4 + (lane >> 4);
+    const bool chain_live = chain < job.n_chains;
+
+    // taps in 1/64 units (adpcm.c:36-37)
+    const int filter = cand / 3;
+    const int which = cand - filter * 3;
+    const bool cand_live = filter < job.filter_count;
+    const int f = cand_live ? filter : 0;
+    const int k1 = f == 0 ? 0 : f == 1 ? 60 : f == 2 ? 115 : f == 3 ? 98 : 122;
+    const int k2 = f == 0 ? 0 : f == 1 ? 0 : f == 2 ? -52 : f == 3 ? -55 : -60;
+
+    const int range = job.range;
+    const int qmin = -0x8000 >> range, qmax = 0x7FFF >> range, qmask = 0xFFFF >> range;
+    const int half = 1 << (range - 1);
+
+    psxhip_adpcm_chain_t ch;
+    ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
+    int prev1 = 0, prev2 = 0;
+    long long rec0 = 0;
+    if (chain_live) {
+        ch = job.chains[chain];
+        prev1 = job.states[chain].prev1;
+        prev2 = job.states[chain].prev2;
+        rec0 = job.unit_base[chain];
+    }
+    // the four chains of a wavefront may have different lengths: iterate to the longest, mask the rest
+    int n_max = ch.n_units;
+    n_max = max(n_max, __shfl_xor(n_max, 16, 64));
+    n_max = max(n_max, __shfl_xor(n_max, 32, 64));
+
+    const int16_t* src = job.samples + ch.sample_offset;
+
+    for (int u = 0; u < n_max; u++) {
+        const bool unit_live = chain_live && u < ch.n_units;
+        const int limit = ch.sample_limit - u * 28;        // samples at i >= limit read as zero (adpcm.c:65,110)
+
+        int x[28];
+#pragma unroll
+        for (int i = 0; i < 28; i++) {
+            int v = 0;
+            if (unit_live && i < limit) v = src[(long long)(u * 28 + i) * ch.pitch];
+            x[i] = v;
+        }
+
+        // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples
+        int lo = 0, hi = 0;
+        {
+            int p1 = prev1, p2 = prev2;
+#pragma unroll
+            for (int i = 0; i < 28; i++) {
+                const int r = x[i] - predict(k1, k2, p1, p2);
+                lo = r < lo ? r : lo;
+                hi = r > hi ? r : hi;
+                p2 = p1;
+                p1 = x[i];
+            }
+        }
+        int rs = 0;
+        while (rs < range && (hi >> rs) > qmax) rs++;
+        while (rs < range && (lo >> rs) < qmin) rs++;
+        const int m = range - rs;
+        const int shift = m - 1 + which;
+        const bool valid = unit_live && cand_live && shift >= 0 && shift <= range;
+        const int sh = valid ? shift : 0;
+
+        // ---- attempt_to_encode for (filter, shift) (adpcm.c:81-140)
+        uint64_t sse = 0;
+        uint32_t packed[7];
+        int p1 = prev1, p2 = prev2;
+#pragma unroll
+        for (int w = 0; w < 7; w++) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = w * 4 + j;
+                const int pred = predict(k1, k2, p1, p2);
+                int q = (int)((uint32_t)(x[i] - pred) << sh);
+                q = (q + half) >> range;
+                q = q < qmin ? qmin : q;
+                q = q > qmax ? qmax : q;
+                q &= qmask;
+                int dec = (int)(int16_t)(uint16_t)(q << range);
+                dec = (dec >> sh) + pred;
+                dec = dec > 0x7FFF ? 0x7FFF : dec;
+                dec = dec < -0x8000 ? -0x8000 : dec;
+                const int err = dec - x[i];
+                sse += (uint64_t)((int64_t)err * (int64_t)err);
+                pk |= (uint32_t)q << (8 * j);
+                p2 = p1;
+                p1 = dec;
+            }
+            packed[w] = pk;
+        }
+
+        // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
+        const uint64_t key = valid ? ((sse << 8) | ((uint64_t)f << 4) | (uint64_t)sh) : ~0ull;
+        const uint64_t best = row_min_u64(key);
+        const bool winner = valid && key == best;
+        const uint64_t wmask = __ballot(winner);
+        const int wlane = (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48);
+        if (winner) {
+            uint32_t* rec = (uint32_t*)(job.units + (rec0 + (long long)u * ch.unit_stride) * kRecordBytes);
+            rec[0] = (uint32_t)((sh & 0x0F) | (f << 4));
+#pragma unroll
+            for (int w = 0; w < 7; w++) rec[1 + w] = packed[w];
+        }
+        const int np1 = __shfl(p1, wlane & 63, 64);
+        const int np2 = __shfl(p2, wlane & 63, 64);
+        if (unit_live) {
+            prev1 = np1;
+            prev2 = np2;
+        }
+    }
+    if (chain_live && cand == 0) {
+        job.states[chain].prev1 = prev1;
+        job.states[chain].prev2 = prev2;
+    }
+}
+
+// ---- SPU block packing (adpcm.c:367-372): [header][flags = 0][14 x (even | odd << 4)]
+__global__ void spu_pack_kernel(const uint8_t* units, int n_blocks, uint8_t* out) {
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= n_blocks) return;
+    const uint32_t* rec = (const uint32_t*)(units + (size_t)b * kRecordBytes);
+    uint32_t o[4];
+    uint8_t bytes[16];
+    bytes[0] = (uint8_t)rec[0];
+    bytes[1] = 0;
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        const uint32_t c = rec[1 + w];
+        bytes[2 + 2 * w] = (uint8_t)((c & 0x0F) | (((c >> 8) & 0x0F) << 4));
+        bytes[3 + 2 * w] = (uint8_t)(((c >> 16) & 0x0F) | (((c >> 24) & 0x0F) << 4));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | ((uint32_t)bytes[4 * k + 3] << 24);
+    uint4 v = {o[0], o[1], o[2], o[3]};
+    *(uint4*)(out + (size_t)b * 16) = v;
+}
+
+// ---- XA sector assembly.  One 256-thread workgroup per sector; the sector is built in LDS as a full
+// 2352-byte raw sector (the .xa form simply skips the first 16 bytes on write-out, adpcm.c:303-311).
+struct XaJob {
+    const uint8_t* units;
+    int n_sectors, format, stereo, frequency, bits, file_number, channel_number, first_lba;
+    const uint8_t* eof_flags;   // optional: eof_flags[s] != 0 sets the EOF submode bit (adpcm.c:334-340)
+    uint8_t* out;
+};
+
+__device__ __forceinline__ uint8_t to_bcd(int v) { return (uint8_t)(v + (v / 10) * 6); }
+
+__global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
+    __shared__ __attribute__((aligned(16))) uint8_t sec[2352];
+    __shared__ uint32_t crc_tab[256];
+    __shared__ uint32_t crc_part[256];
+    __shared__ uint32_t zmat[8][32];   // zmat[k][b]: CRC state (1 << b) advanced over 10 * 2^k zero bytes
+    const int tid = (int)threadIdx.x;
+    const int s = (int)blockIdx.x;
+    const bool four = job.bits == 4;
+    const int upg = four ? 8 : 4;                 // sound units per group
+    const int sector_size = job.format == 0 ? 2336 : 2352;
+
+    // reflected CRC-32 table for polynomial 0xD8018001 (cdrom.c:28-41)
+    {
+        uint32_t v = (uint32_t)tid;
+        for (int k = 0; k < 8; k++) v = (v >> 1) ^ ((v & 1u) ? 0xD8018001u : 0u);
+        crc_tab[tid] = v;
+    }
+    for (int i = tid; i < 2352 / 4; i += 256) ((uint32_t*)sec)[i] = 0u;
+    __syncthreads();
+    if (tid < 32) {
+        uint32_t v = 1u << tid;
+        for (int i = 0; i < 10; i++) v = (v >> 8) ^ crc_tab[v & 0xFF];
+        zmat[0][tid] = v;
+    }
+    __syncthreads();
+    for (int k = 1; k < 8; k++) {
+        if (tid < 32) {
+            const uint32_t v = zmat[k - 1][tid];
+            uint32_t r = 0;
+            for (int bit = 0; bit < 32; bit++)
+                if ((v >> bit) & 1u) r ^= zmat[k - 1][bit];
+            zmat[k][tid] = r;
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        if (job.format == 1) {       // psx_cdrom_init_sector, mode 2 (cdrom.c:55-74)
+            for (int i = 1; i <= 10; i++) sec[i] = 0xFF;
+            const int lba = job.first_lba + s + 150;
+            sec[12] = to_bcd(lba / 4500);
+            sec[13] = to_bcd((lba / 75) % 60);
+            sec[14] = to_bcd(lba % 75);
+            sec[15] = 0x02;
+        }
+        sec[16] = (uint8_t)job.file_number;
+        sec[17] = (uint8_t)(job.channel_number & 0x1F);
+        sec[18] = (uint8_t)(0x04 | 0x20 | 0x40);   // AUDIO | FORM2 | RT
+        sec[19] = (uint8_t)((job.stereo ? 0x01 : 0) | (job.frequency == 37800 ? 0 : 0x04) | (four ? 0 : 0x10));
+        sec[20] = sec[16]; sec[21] = sec[17]; sec[22] = sec[18]; sec[23] = sec[19];
+    }
+
+    // sound groups: 18 x 128 bytes at sector offset 0x18 (adpcm.c:193-233,311-322)
+    const uint8_t* rec0 = job.units + (size_t)s * 18 * upg * kRecordBytes;
+    for (int i = tid; i < 18 * 128; i += 256) {
+        const int g = i >> 7, b = i & 127;
+        const uint8_t* gr = rec0 + (size_t)g * upg * kRecordBytes;
+        uint8_t v;
+        if (b < 16) {
+            // header bytes: 4-bit: units {0,1,2,3} at 0..3 and 4..7, units {4..7} at 8..11 and 12..15;
+            // 8-bit: units 0..3 at 0..3 and 4..7, bytes 8..15 are never written by the reference (stay 0)
+            const int unit = four ? ((b & 3) | ((b & 8) >> 1)) : (b & 3);
+            v = (four || b < 8) ? gr[unit * kRecordBytes] : 0;
+        } else {
+            const int w = (b - 16) >> 2, col = (b - 16) & 3;          // sample index, byte column
+            if (four) {
+                const uint8_t lo = gr[(2 * col) * kRecordBytes + 4 + w];
+                const uint8_t hi = gr[(2 * col + 1) * kRecordBytes + 4 + w];
+                v = (uint8_t)((lo & 0x0F) | (hi << 4));
+            } else {
+                v = gr[col * kRecordBytes + 4 + w];
+            }
+        }
+        sec[0x18 + i] = v;
+    }
+    __syncthreads();
+
+    // form-2 EDC over sector bytes 0x10 .. 0x92B (0x91C = 2332 bytes) -> 0x92C (cdrom.c:102-110).
+    // The CRC has zero init and no final xor, so it is linear over GF(2): the CRC of the span is the xor of
+    // the CRCs of its chunks, each advanced over the zero bytes that follow it.  The span is viewed as
+    // 256 chunks of 10 bytes (228 leading zero bytes of padding change nothing); thread t owns chunk t and
+    // advances its partial by 10 * (255 - t) zero bytes using the power-of-two "append zeros" matrices zmat.
+    {
+        constexpr int kChunk = 10, kTotal = 0x91C, kPad = 256 * kChunk - kTotal;
+        uint32_t c = 0;
+        for (int i = 0; i < kChunk; i++) {
+            const int at = tid * kChunk + i - kPad;
+            if (at >= 0) c = (c >> 8) ^ crc_tab[(c ^ sec[0x10 + at]) & 0xFF];
+        }
+        const int tail_chunks = 255 - tid;
+        for (int k = 0; k < 8; k++) {
+            if ((tail_chunks >> k) & 1) {
+                uint32_t r = 0;
+                for (int bit = 0; bit < 32; bit++)
+                    if ((c >> bit) & 1u) r ^= zmat[k][bit];
+                c = r;
+            }
+        }
+        crc_part[tid] = c;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (tid < off) crc_part[tid] ^= crc_part[tid + off];
+            __syncthreads();
+        }
+        if (tid < 4) sec[0x92C + tid] = (uint8_t)(crc_part[0] >> (8 * tid));
+        // psx_audio_xa_encode_finalize (adpcm.c:334-340) ORs EOF into both subheader copies AFTER the EDC was
+        // computed and does not refresh it; kept that way for byte parity.
+        if (tid == 4 && job.eof_flags && job.eof_flags[s]) {
+            sec[18] |= 0x80;
+            sec[22] = sec[18];
+        }
+    }
+    __syncthreads();
+
+    const int lead = 2352 - sector_size;
+    uint8_t* dst = job.out + (size_t)s * sector_size;
+    for (int i = tid; i < sector_size / 4; i += 256) ((uint32_t*)dst)[i] = *(const uint32_t*)&sec[lead + 4 * i];
+}
+
+}  // namespace
+
+int psxhip_ensure_device(int device);
+
+extern "C" int psxhip_adpcm_encode_chains_device(int device, const int16_t* d_samples, const psxhip_adpcm_chain_t* d_chains,
+                                                 const int32_t* d_unit_base, int n_chains, int filter_count, int bits,
+                                                 psxhip_adpcm_state_t* d_states, uint8_t* d_units, void* stream) {
+    if (!d_samples || !d_chains || !d_unit_base || !d_states || !d_units || n_chains < 0 ||
+        (filter_count != 4 && filter_count != 5) || (bits != 4 && bits != 8) || ((uintptr_t)d_units & 3)) {
+        psxhip_set_error("adpcm_encode_chains: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    if (n_chains == 0) return PSXHIP_OK;
+    ChainJob job;
+    job.samples = d_samples;
+    job.chains = d_chains;
+    job.unit_base = d_unit_base;
+    job.n_chains = n_chains;
+    job.filter_count = filter_count;
+    job.range = bits == 4 ? 12 : 8;
+    job.states = d_states;
+    job.units = d_units;
+    hipLaunchKernelGGL(adpcm_chains_kernel, dim3((unsigned)((n_chains + 3) / 4)), dim3(64), 0, (hipStream_t)stream, job);
+    if (hipGetLastError() != hipSuccess) {
+        psxhip_set_error("adpcm_encode_chains: launch failed");
+        return PSXHIP_EDEVICE;
+    }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_spu_pack_device(int device, const uint8_t* d_units, int n_blocks, uint8_t* d_out, void* stream) {
+    if (!d_units || !d_out || n_blocks < 0 || ((uintptr_t)d_out & 15) || ((uintptr_t)d_units & 3)) {
+        psxhip_set_error("spu_pack: bad argument (d_out must be 16-byte aligned)");
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    if (n_blocks == 0) return PSXHIP_OK;
+    hipLaunchKernelGGL(spu_pack_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_units,
+                       n_blocks, d_out);
+    if (hipGetLastError() != hipSuccess) {
+        psxhip_set_error("spu_pack: launch failed");
+        return PSXHIP_EDEVICE;
+    }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_xa_assemble_device(int device, const uint8_t* d_units, int n_sectors, int format, int stereo,
+                                         int frequency, int bits, int file_number, int channel_number, int first_lba,
+                                         const uint8_t* d_eof_flags, uint8_t* d_out, void* stream) {
+    if (!d_units || !d_out || n_sectors < 0 || (format != 0 && format != 1) || (bits != 4 && bits != 8) ||
+        ((uintptr_t)d_out & 3)) {
+        psxhip_set_error("xa_assemble: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    if (n_sectors == 0) return PSXHIP_OK;
+    XaJob job;
+    job.units = d_units;
+    job.n_sectors = n_sectors;
+    job.format = format;
+    job.stereo = stereo;
+    job.frequency = frequency;
+    job.bits = bits;
+    job.file_number = file_number;
+    job.channel_number = channel_number;
+    job.first_lba = first_lba;
+    job.eof_flags = d_eof_flags;
+    job.out = d_out;
+    hipLaunchKernelGGL(xa_assemble_kernel, dim3((unsigned)n_sectors), dim3(256), 0, (hipStream_t)stream, job);
+    if (hipGetLastError() != hipSuccess) {
+        psxhip_set_error("xa_assemble: launch failed");
+        return PSXHIP_EDEVICE;
+    }
+    return PSXHIP_OK;
+}

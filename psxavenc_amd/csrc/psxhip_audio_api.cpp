@@ -1,0 +1,153 @@
+// psxhip_audio_api.cpp -- host-buffer batches for the ADPCM path (include/psxav_hip.h): build the chain
+// descriptors, move buffers, launch the chain / pack / assemble kernels.  No encoding happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "psxhip_internal.h"
+
+int psxhip_ensure_device(int device);
+
+namespace {
+
+#define HIP_TRY(expr, code)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            psxhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (code);                                                                    \
+        }                                                                                     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples, int n_streams, int64_t stream_stride,
+                                              int pitch, int samples_per_stream, psxhip_adpcm_state_t* states,
+                                              uint8_t* out, int64_t out_stride) {
+    if (!samples || !states || !out || n_streams < 0 || samples_per_stream < 0 || pitch < 1) {
+        psxhip_set_error("spu_encode_streams_host: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    const int n_units = (samples_per_stream + 27) / 28;
+    const int bytes = n_units * 16;
+    if (n_streams == 0 || n_units == 0) return bytes;
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+
+    const size_t per = (size_t)samples_per_stream * pitch;          // elements copied per stream
+    std::vector<psxhip_adpcm_chain_t> chains(n_streams);
+    std::vector<int32_t> base(n_streams);
+    for (int i = 0; i < n_streams; i++) {
+        chains[i].sample_offset = (int64_t)i * (int64_t)per;
+        chains[i].pitch = pitch;
+        chains[i].sample_limit = samples_per_stream;
+        chains[i].n_units = n_units;
+        chains[i].unit_stride = 1;
+        base[i] = i * n_units;
+    }
+    DevBuf d_s, d_c, d_b, d_st, d_u, d_o;
+    HIP_TRY(d_s.alloc(per * n_streams * sizeof(int16_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_c.alloc(chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
+    HIP_TRY(d_b.alloc(base.size() * sizeof(int32_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_st.alloc(n_streams * sizeof(psxhip_adpcm_state_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_u.alloc((size_t)n_streams * n_units * PSXHIP_ADPCM_RECORD_BYTES), PSXHIP_ENOMEM);
+    HIP_TRY(d_o.alloc((size_t)n_streams * bytes), PSXHIP_ENOMEM);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipMemcpy2DAsync(d_s.p, per * sizeof(int16_t), samples, (size_t)stream_stride * sizeof(int16_t),
+                             per * sizeof(int16_t), (size_t)n_streams, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_c.p, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_st.p, states, n_streams * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
+                                           n_streams, 5, 4, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
+    if (rc) return rc;
+    rc = psxhip_spu_pack_device(device, d_u.as<uint8_t>(), n_streams * n_units, d_o.as<uint8_t>(), st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride, d_o.p, (size_t)bytes, (size_t)bytes, (size_t)n_streams,
+                             hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(states, d_st.p, n_streams * sizeof(psxhip_adpcm_state_t), hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+    return bytes;
+}
+
+extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo, int frequency, int bits, int file_number,
+                                             int channel_number, const int16_t* samples, int n_streams,
+                                             int64_t stream_stride, int samples_per_stream, const int32_t* lbas,
+                                             psxhip_adpcm_state_t* states, uint8_t* out, int64_t out_stride, int finalize) {
+    if (!samples || !states || !out || n_streams < 0 || samples_per_stream < 0 || (bits != 4 && bits != 8) ||
+        (format != 0 && format != 1)) {
+        psxhip_set_error("xa_encode_streams_host: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    const int ch = stereo ? 2 : 1;
+    const int upg = bits == 4 ? 8 : 4;                         // units per 128-byte sound group
+    const int group_samples = upg * 28;                        // interleaved samples consumed per group (adpcm.c:301)
+    const int64_t total = (int64_t)samples_per_stream * ch;    // adpcm.c:307-308
+    const int groups = (int)((total + group_samples - 1) / group_samples);
+    const int sectors = (groups + 17) / 18;                    // the loop runs until the sector is complete (adpcm.c:310)
+    const int ssz = format == 0 ? 2336 : 2352;
+    const int bytes = sectors * ssz;
+    if (n_streams == 0 || sectors == 0) return bytes;
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+
+    const int units_per_stream = sectors * 18 * upg;
+    const int units_per_chain = units_per_stream / ch;
+    const size_t per = (size_t)total;
+    std::vector<psxhip_adpcm_chain_t> chains((size_t)n_streams * ch);
+    std::vector<int32_t> base((size_t)n_streams * ch);
+    for (int i = 0; i < n_streams; i++)
+        for (int c = 0; c < ch; c++) {
+            psxhip_adpcm_chain_t& d = chains[(size_t)i * ch + c];
+            d.sample_offset = (int64_t)i * (int64_t)per + c;
+            d.pitch = ch;
+            d.sample_limit = samples_per_stream;
+            d.n_units = units_per_chain;
+            d.unit_stride = ch;
+            base[(size_t)i * ch + c] = i * units_per_stream + c;
+        }
+    std::vector<uint8_t> eof((size_t)n_streams * sectors, 0);
+    if (finalize)
+        for (int i = 0; i < n_streams; i++) eof[(size_t)i * sectors + sectors - 1] = 1;
+
+    DevBuf d_s, d_c, d_b, d_st, d_u, d_o, d_e;
+    HIP_TRY(d_s.alloc(per * n_streams * sizeof(int16_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_c.alloc(chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
+    HIP_TRY(d_b.alloc(base.size() * sizeof(int32_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_st.alloc(chains.size() * sizeof(psxhip_adpcm_state_t)), PSXHIP_ENOMEM);
+    HIP_TRY(d_u.alloc((size_t)n_streams * units_per_stream * PSXHIP_ADPCM_RECORD_BYTES), PSXHIP_ENOMEM);
+    HIP_TRY(d_o.alloc((size_t)n_streams * bytes), PSXHIP_ENOMEM);
+    HIP_TRY(d_e.alloc(eof.size()), PSXHIP_ENOMEM);
+    hipStream_t st = nullptr;
+    if (per)
+        HIP_TRY(hipMemcpy2DAsync(d_s.p, per * sizeof(int16_t), samples, (size_t)stream_stride * sizeof(int16_t),
+                                 per * sizeof(int16_t), (size_t)n_streams, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_c.p, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_st.p, states, chains.size() * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(d_e.p, eof.data(), eof.size(), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+    rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
+                                           (int)chains.size(), 4, bits, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
+    if (rc) return rc;
+    for (int i = 0; i < n_streams; i++) {
+        rc = psxhip_xa_assemble_device(device, d_u.as<uint8_t>() + (size_t)i * units_per_stream * PSXHIP_ADPCM_RECORD_BYTES,
+                                       sectors, format, stereo, frequency, bits, file_number, channel_number,
+                                       lbas ? lbas[i] : 0, d_e.as<uint8_t>() + (size_t)i * sectors,
+                                       d_o.as<uint8_t>() + (size_t)i * bytes, st);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride, d_o.p, (size_t)bytes, (size_t)bytes, (size_t)n_streams,
+                             hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(states, d_st.p, chains.size() * sizeof(psxhip_adpcm_state_t), hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+    return bytes;
+}
