@@ -40,6 +40,11 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     const int n_units = (samples_per_stream + 27) / 28;
     const int bytes = n_units * 16;
     if (n_streams == 0 || n_units == 0) return bytes;
+    if (n_streams == 1) out_stride = bytes;     /* a single stream needs no pitch */
+    if (out_stride < bytes) {
+        psxhip_set_error("spu_encode_streams_host: out_stride %lld < %d bytes per stream", (long long)out_stride, bytes);
+        return PSXHIP_EINVAL;
+    }
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
 
@@ -97,6 +102,11 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
     const int ssz = format == 0 ? 2336 : 2352;
     const int bytes = sectors * ssz;
     if (n_streams == 0 || sectors == 0) return bytes;
+    if (n_streams == 1) out_stride = bytes;
+    if (out_stride < bytes) {
+        psxhip_set_error("xa_encode_streams_host: out_stride %lld < %d bytes per stream", (long long)out_stride, bytes);
+        return PSXHIP_EINVAL;
+    }
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
 

@@ -1,0 +1,182 @@
+"""The reference's own call patterns, driven through the drop-in C functions of libpsxav_hip.so with the
+reference's struct layouts (ctypes): encode_file_sbs (filefmt.c:633-662), encode_file_str for config
+'strcd v2' (filefmt.c:391-520) and encode_file_spu for config 'spu' (filefmt.c:212-293), each diffed
+against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+class MdecState(C.Structure):           # mdec_encoder_state_t, include/psxav_mdec.h (psxavenc/mdec.h:32-55)
+    _fields_ = [("frame_index", C.c_int), ("frame_data_offset", C.c_int), ("frame_max_size", C.c_int),
+                ("frame_block_base_overflow", C.c_int), ("frame_block_overflow_num", C.c_int),
+                ("frame_block_overflow_den", C.c_int), ("block_type", C.c_int), ("last_dc_values", C.c_int16 * 3),
+                ("bits_value", C.c_uint16), ("bits_left", C.c_int), ("frame_output", C.c_void_p),
+                ("bytes_used", C.c_int), ("blocks_used", C.c_int), ("uncomp_hwords_used", C.c_int),
+                ("quant_scale", C.c_int), ("quant_scale_sum", C.c_int), ("dct_context", C.c_void_p),
+                ("ac_huffman_map", C.c_void_p), ("dc_huffman_map", C.c_void_p), ("coeff_clamp_map", C.c_void_p),
+                ("dct_block_lists", C.c_void_p * 6)]
+
+
+class MdecEncoderT(C.Structure):        # mdec_encoder_t
+    _fields_ = [("video_codec", C.c_int), ("video_width", C.c_int), ("video_height", C.c_int), ("state", MdecState)]
+
+
+class XaSettingsT(C.Structure):         # psx_audio_xa_settings_t
+    _fields_ = [("format", C.c_int), ("stereo", C.c_bool), ("frequency", C.c_int), ("bits_per_sample", C.c_int),
+                ("file_number", C.c_int), ("channel_number", C.c_int)]
+
+
+class ChanT(C.Structure):               # psx_audio_encoder_channel_state_t
+    _fields_ = [("qerr", C.c_int), ("mse", C.c_uint64), ("prev1", C.c_int), ("prev2", C.c_int)]
+
+
+class StateT(C.Structure):
+    _fields_ = [("left", ChanT), ("right", ChanT)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from psxavenc_amd import _lib
+    lib = _lib.lib()
+    lib.init_mdec_encoder.argtypes = [C.POINTER(MdecEncoderT), C.c_int, C.c_int, C.c_int]
+    lib.init_mdec_encoder.restype = C.c_bool
+    lib.destroy_mdec_encoder.argtypes = [C.POINTER(MdecEncoderT)]
+    lib.encode_frame_bs.argtypes = [C.POINTER(MdecEncoderT), C.c_void_p]
+    lib.encode_frame_bs.restype = None
+    lib.encode_sector_str.argtypes = [C.POINTER(MdecEncoderT), C.c_int, C.c_uint16, C.c_void_p, C.c_void_p]
+    lib.psx_audio_spu_encode.argtypes = [C.POINTER(ChanT), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.psx_audio_spu_encode_simple.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.psx_audio_xa_encode.argtypes = [XaSettingsT, C.POINTER(StateT), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.psx_audio_xa_encode_finalize.argtypes = [XaSettingsT, C.c_void_p, C.c_int]
+    lib.psx_audio_xa_get_samples_per_sector.argtypes = [XaSettingsT]
+    lib.psx_audio_xa_get_sector_interleave.argtypes = [XaSettingsT]
+    lib.psx_cdrom_init_sector.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.psx_cdrom_calculate_checksums.argtypes = [C.c_void_p, C.c_int]
+    return lib
+
+
+def test_encode_file_sbs_loop(L):
+    w, h, align, n = 320, 240, 8192, 6
+    fr = O.synth_frames(w, h, n, seed=31, amp=8)
+    want, want_res, _ = O.mdec_encode(0, w, h, fr, align)
+    enc = MdecEncoderT()
+    assert L.init_mdec_encoder(C.byref(enc), 0, w, h)
+    out = np.zeros(align, np.uint8)
+    enc.state.frame_output = out.ctypes.data          # the caller owns frame_output (filefmt.c:637)
+    enc.state.frame_data_offset = 0
+    enc.state.frame_max_size = align
+    enc.state.quant_scale_sum = 0
+    for j in range(n):
+        L.encode_frame_bs(C.byref(enc), fr[j].ctypes.data)
+        assert np.array_equal(out, want[j]), j
+        assert [enc.state.quant_scale, enc.state.bytes_used, enc.state.blocks_used, enc.state.uncomp_hwords_used] == want_res[j].tolist()
+    assert enc.state.quant_scale_sum == int(want_res[:, 0].sum())
+    L.destroy_mdec_encoder(C.byref(enc))
+    L.destroy_mdec_encoder(C.byref(enc))                # idempotent (mdec.c:553-578)
+    assert not enc.state.dct_context
+
+
+def test_encode_file_str_strcd_config(L):
+    """config 'strcd v2': 320x240 @15 fps, 2x speed, 37800 Hz 4-bit stereo XA: interleave 8 (1 audio : 7 video),
+    budgets cycling 16128 / 18144 x3.  Whole sector stream vs the oracle's restatement."""
+    w, h, fps_num, fps_den, cd_speed, n_frames = 320, 240, 15, 1, 2, 5
+    xs = XaSettingsT(1, True, 37800, 4, 1, 0)
+    oxs = O.XaSettings(1, 1, 37800, 4, 1, 0)
+    interleave = L.psx_audio_xa_get_sector_interleave(xs) * cd_speed
+    assert interleave == 8
+    sps = L.psx_audio_xa_get_samples_per_sector(xs)
+    vspb = interleave - 1
+    fr = O.synth_frames(w, h, n_frames + 1, seed=8, amp=8)
+    n_audio = 8
+    pcm = np.zeros((n_audio * sps + 4032) * 2, np.int16)
+    pcm[0:2 * n_audio * sps:2] = O.synth_pcm(4, 0, 0, n_audio * sps, 0)
+    pcm[1:2 * n_audio * sps:2] = O.synth_pcm(4, 1, 0, n_audio * sps, 0)
+
+    enc = MdecEncoderT()
+    assert L.init_mdec_encoder(C.byref(enc), 0, w, h)
+    base = 75 * cd_speed * vspb * fps_den
+    den = interleave * fps_num
+    cap = 2016 * -(-base // den)
+    fo = np.zeros(cap, np.uint8)
+    enc.state.frame_block_base_overflow = base
+    enc.state.frame_block_overflow_den = den
+    enc.state.frame_output = fo.ctypes.data
+    enc.state.frame_index = 0
+    enc.state.frame_data_offset = 0
+    enc.state.frame_max_size = 0
+    enc.state.frame_block_overflow_num = 0
+    enc.state.quant_scale_sum = 0
+    astate = StateT()
+
+    ofo = np.zeros(cap, np.uint8)
+    ost = O.StrState(0, 0, 0, base, 0, den, 0, 0, ofo.ctypes.data)
+    oastate = O.State()
+
+    budgets = []
+    frame_cursor, audio_cursor = 0, 0
+    for sector_count in range(44):
+        got = np.zeros(2352, np.uint8)
+        want = np.zeros(2352, np.uint8)
+        if sector_count % interleave > 0:
+            if frame_cursor >= n_frames and enc.state.frame_data_offset >= enc.state.frame_max_size:
+                break
+            L.psx_cdrom_init_sector(got.ctypes.data, sector_count, 1)          # init_sector_buffer_video, filefmt.c:73-91
+            got[16:20] = [1, 0, 0x08 | 0x40, 0]
+            got[20:24] = got[16:20]
+            used = L.encode_sector_str(C.byref(enc), 7, 0x8001, fr[frame_cursor].ctypes.data, got.ctypes.data)
+            L.psx_cdrom_calculate_checksums(got.ctypes.data, 1)
+            O.lib().orc_cdrom_init_sector(O.ptr(want, O.u8p), sector_count, 1)
+            want[16:20] = [1, 0, 0x08 | 0x40, 0]
+            want[20:24] = want[16:20]
+            oused = O.lib().orc_mdec_encode_sector_str(C.byref(ost), 0, w, h, O.FMT_STRCD, 0x8001, O.ptr(fr[frame_cursor], O.u8p), O.ptr(want, O.u8p))
+            O.lib().orc_cdrom_calculate_checksums(O.ptr(want, O.u8p), 1)
+            assert used == oused
+            if used:
+                budgets.append(enc.state.frame_max_size)
+            frame_cursor += used
+        else:
+            chunk = pcm[2 * audio_cursor:]
+            ln = L.psx_audio_xa_encode(xs, C.byref(astate), chunk.ctypes.data, sps, sector_count, got.ctypes.data)
+            w_, oastate = O.xa_encode(oxs, chunk, sps, lba=sector_count, state=oastate)
+            assert ln == 2352
+            want[:] = w_
+            audio_cursor += sps
+        assert np.array_equal(got, want), sector_count
+    assert budgets[:5] == [16128, 18144, 18144, 18144, 16128]
+    assert enc.state.quant_scale_sum == ost.quant_scale_sum and enc.state.frame_index == ost.frame_index
+    L.destroy_mdec_encoder(C.byref(enc))
+
+
+def test_encode_file_spu_config(L):
+    """config 'spu': mono 22050 Hz 1 s sine -> leading dummy block, 788 blocks by 28-sample calls, trap block,
+    padded to 64-byte alignment: 12672 bytes"""
+    i = np.arange(22050)
+    sine = np.rint(16384 * np.sin(2 * np.pi * 440 * i / 22050)).astype(np.int16)
+    st, ost = ChanT(), O.Chan(0, 0)
+    blocks, oblocks = [np.zeros(16, np.uint8)], [np.zeros(16, np.uint8)]
+    for pos in range(0, sine.size, 28):
+        cnt = min(28, sine.size - pos)
+        blk = np.zeros(16, np.uint8)
+        ln = L.psx_audio_spu_encode(C.byref(st), sine[pos:].ctypes.data, cnt, 1, blk.ctypes.data)
+        assert ln == 16
+        blocks.append(blk)
+        oblk, ost = O.spu_encode(sine[pos:pos + cnt], state=ost, n=cnt)
+        oblocks.append(oblk)
+    trap = np.zeros(16, np.uint8)
+    trap[1] = 5
+    got = np.concatenate(blocks + [trap])
+    want = np.concatenate(oblocks + [trap])
+    assert got.size == 12640 and np.array_equal(got, want)
+    pad = (-got.size) % 64
+    assert got.size + pad == 12672
+    assert got[16:20].tobytes() == bytes([0x24, 0x00, 0x70, 0x13])
+    # and the one-shot convenience entry point
+    buf = np.zeros(13000, np.uint8)
+    ln = L.psx_audio_spu_encode_simple(sine.ctypes.data, sine.size, buf.ctypes.data, -1)
+    assert ln == 12624 and np.array_equal(buf[:ln - 16], got[16:16 + ln - 16])
