@@ -73,6 +73,12 @@ int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t *ctx, const uint8_t *frames
 /* Name and grid of the kernel the last encode call launched (for bench.py's roofline block). */
 const char *psxhip_mdec_kernel_name(void);
 
+/* Diagnostics: when the context was created with PSXHIP_MDEC_TIMING=1 in the environment, the kernel
+ * accumulates shader-clock cycles per phase (summed over workgroups): 0 reset, 1 DCT + first count pass,
+ * 2 DC chain, 3 rate control (incl. further count passes), 4 offset scan, 5 emit, 6 finalise + write-out.
+ * Zeros otherwise. */
+int psxhip_mdec_read_timing(psxhip_mdec_ctx_t *ctx, unsigned long long *out8, int reset);
+
 /* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */
 
 /* carried state of one channel: the last two DECODED samples (libpsxav/adpcm.c:135-136).  The

@@ -35,7 +35,7 @@ constexpr int kScalesPerPass = 4;
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
 
 __constant__ uint8_t c_ac_len[BS_LUT_SIZE];
-__constant__ uint16_t c_ac_code[BS_LUT_SIZE];
+__constant__ uint32_t c_ac_code[BS_LUT_SIZE];
 __constant__ uint8_t c_zagzig[64];
 __constant__ uint8_t c_quant_zz[64];
 __constant__ uint8_t c_dc_prefix[2][8];   // [0] chroma, [1] luma
@@ -53,6 +53,7 @@ struct FrameJob {
     psxhip_mdec_result_t* results;
     int16_t* coef_slab;      // [gridDim.x][nmb][6][64], zig-zag order
     int out_words;           // LDS dwords reserved for one frame's output
+    unsigned long long* timing;   // optional [8] phase cycle counters (diagnostics), NULL in normal runs
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -100,6 +101,23 @@ __device__ __forceinline__ void fdct8(int (&d)[8]) {
     d[1] = (o3 + z1 + z4 + RND) >> SH;
 }
 
+// diagnostics: thread 0 of a workgroup accumulates s_memtime deltas per phase
+struct PhaseClock {
+    unsigned long long* dst;
+    unsigned long long last;
+    __device__ __forceinline__ void start(unsigned long long* d) {
+        dst = d;
+        if (dst && threadIdx.x == 0) last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void mark(int phase) {
+        if (dst && threadIdx.x == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(&dst[phase], now - last);
+            last = now;
+        }
+    }
+};
+
 // wave-level ordering point for LDS traffic between lanes of the same wavefront
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -127,21 +145,14 @@ __device__ __forceinline__ int quant_dc(int c0) {
     return v < -512 ? -512 : (v > 510 ? 510 : v);
 }
 
-// length in bits of the v3 DC code for a (possibly wrapped) delta; luma = 1 for Y blocks
-__device__ __forceinline__ int dc_delta_len(int delta, int luma, const uint8_t* plen /* [2][8] in LDS */) {
-    if (delta == 0) return luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
-    const int a = delta < 0 ? -delta : delta;
-    const int m = 31 - __builtin_clz((unsigned)a);
-    return plen[luma * 8 + m] + 1 + m;
-}
-
 struct Lds {
     uint32_t* out;          // [out_words]           frame output staging, dword j = output bytes 4j..4j+3 (pre-swizzle)
     uint16_t* mb_bits;      // [nmb][kScalesPerPass] AC bits of each macroblock at each scale of the pass
     uint32_t* mb_off;       // [nmb]                 bit offset of each macroblock in the chosen bitstream
-    int16_t* dcq;           // [nmb*6]               quantised DC (v2) / DC delta (v3) per block, encode order
+    uint32_t* dcw;          // [nmb*6]               per block, encode order: quantised DC (int) during pass 1, then the
+                            //                       DC code as bits << 24 | code
     uint8_t* ac_len;        // [BS_LUT_SIZE]
-    uint16_t* ac_code;      // [BS_LUT_SIZE]
+    uint32_t* ac_code;      // [BS_LUT_SIZE]      bits << 24 | code
     uint8_t* dc_plen;       // [16]
     uint8_t* dc_prefix;     // [16]
     int16_t* tiles;         // per-wave DCT staging
@@ -157,11 +168,10 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
     b += (size_t)nmb * kScalesPerPass * 2;
     b = (b + 3) & ~(size_t)3;
     b += (size_t)nmb * 4;
-    b += (size_t)nmb * 6 * 2;
-    b = (b + 3) & ~(size_t)3;
+    b += (size_t)nmb * 6 * 4;
     b += BS_LUT_SIZE;             // ac_len
     b = (b + 3) & ~(size_t)3;
-    b += BS_LUT_SIZE * 2;         // ac_code
+    b += BS_LUT_SIZE * 4;         // ac_code
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kWavesPerGroup * kWaveTileBytes;
@@ -175,9 +185,9 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words) {
     L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
     L.mb_bits = (uint16_t*)(base + b);    b += (size_t)nmb * kScalesPerPass * 2;  b = (b + 3) & ~(size_t)3;
     L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
-    L.dcq = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
+    L.dcw = (uint32_t*)(base + b);        b += (size_t)nmb * 6 * 4;
     L.ac_len = (uint8_t*)(base + b);      b += BS_LUT_SIZE;                        b = (b + 3) & ~(size_t)3;
-    L.ac_code = (uint16_t*)(base + b);    b += BS_LUT_SIZE * 2;
+    L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
     L.tiles = (int16_t*)(base + b);       b += (size_t)kWavesPerGroup * kWaveTileBytes;
@@ -200,32 +210,33 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t pos, int len,
 struct LaneConst {
     int quant;          // quant matrix entry at this zig-zag position
     uint64_t below;     // mask of lanes below this one
+    int lane_m64;       // lane - 64
 };
 
-// AC bits of one block at one scale; also returns the ballot of non-zero levels (wave-uniform).
-// coef is this lane's coefficient; lane 0 (DC) never participates.
-__device__ __forceinline__ int ac_block_bits(int two_abs, bool neg, int d, float inv2d, const LaneConst& lc,
-                                             const uint8_t* ac_len, int lane, uint64_t& mask_out, int& level_out,
-                                             int& run_out) {
-    int q = quant_level(two_abs, d, inv2d);
-    const int lim = neg ? 512 : 510;
+// One block at one scale, branch-free: quantised magnitude `q`, run of zeros before this lane, and the
+// index of (run, q) in the padded LUTs (level 0 -> column 0 -> 0 bits, so silent lanes need no predicate).
+// `two_abs_f` = float(2|n|), 0 on lane 0 (the DC slot never carries an AC code); `lim` = 512 for negative
+// coefficients, 510 for positive ones (clamp range, mdec.c:260-267); `inv2d` = 1/(2 quant scale),
+// `bias` = 0.5 + 0.5 * inv2d.
+struct AcEval {
+    uint64_t mask;   // ballot of non-zero levels (bit 0 never set)
+    int q, run, idx;
+};
+__device__ __forceinline__ AcEval ac_eval(float two_abs_f, int lim, float inv2d, float bias, const LaneConst& lc) {
+    AcEval e;
+    // floor((2|n| + d) / 2d) with d / 2d = 0.5 folded into the addend: trunc(fma(2|n|, 1/2d, 0.5 + 0.5/2d)).
+    // Same argument as quant_level(): the exact value is >= 0.5/2d away from every integer, the computed one
+    // is within (2|n| + d) * 1.5 * 2^-23 / 2d + 2^-25 of it (tests/test_mdec_oracle.py checks every operand).
+    int q = (int)__builtin_fmaf(two_abs_f, inv2d, bias);
     q = q > lim ? lim : q;
-    const bool nz = (q != 0) && (lane != 0);
-    const uint64_t mask = wave::ballot(nz);
-    const uint64_t prev = (mask & lc.below) | 1ull;            // bit 0 = the DC slot, acts as "previous coefficient" sentinel
-    const int run = lane - 1 - (63 - __builtin_clzll(prev));
-    int len = 0;
-    if (nz) {
-        len = BS_ESCAPE_BITS;
-        if (run <= BS_LUT_MAX_RUN && q <= BS_LUT_MAX_LEVEL) {
-            const int l = ac_len[run * BS_LUT_W + q];
-            len = l ? l : BS_ESCAPE_BITS;
-        }
-    }
-    mask_out = mask;
-    level_out = q;
-    run_out = run;
-    return len;
+    e.mask = wave::ballot(q != 0);
+    const uint64_t prev = (e.mask | 1ull) & lc.below;      // bit 0 = the DC slot, the "previous coefficient" sentinel
+    e.run = __clzll((long long)prev) + lc.lane_m64;        // lane - 1 - (63 - clz)
+    e.q = q;
+    const int rc = e.run > BS_LUT_MAX_RUN + 1 ? BS_LUT_MAX_RUN + 1 : e.run;
+    const int qc = q > BS_LUT_MAX_LEVEL + 1 ? BS_LUT_MAX_LEVEL + 1 : q;
+    e.idx = rc * BS_LUT_W + qc;
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
     LaneConst lc;
     lc.quant = c_quant_zz[lane];
     lc.below = (1ull << lane) - 1ull;
+    lc.lane_m64 = lane - 64;
 
     // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3)
     int zpos[8];
@@ -273,6 +285,9 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
 
     int16_t* slab = job.coef_slab + (size_t)blockIdx.x * nmb * 384;
 
+    PhaseClock clk;
+    clk.start(job.timing);
+
     for (int f = (int)blockIdx.x; f < job.n_frames; f += (int)gridDim.x) {
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
         const int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
@@ -283,42 +298,61 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
         if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
         if (tid < 8) L.scalars[tid] = 0;
         __syncthreads();
+        clk.mark(0);
 
         // =====================================================================================
         // Pass 1: DCT of every macroblock + AC bit counts for scales 1..kScalesPerPass
         // =====================================================================================
-        int dq[kScalesPerPass];
-        float inv[kScalesPerPass];
+        float inv[kScalesPerPass], bias[kScalesPerPass];
 #pragma unroll
         for (int s = 0; s < kScalesPerPass; s++) {
-            dq[s] = lc.quant * (1 + s);
-            inv[s] = 1.0f / (float)(2 * dq[s]);
+            inv[s] = 1.0f / (float)(2 * lc.quant * (1 + s));
+            bias[s] = 0.5f + 0.5f * inv[s];
         }
         int wave_tot[kScalesPerPass];
 #pragma unroll
         for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
 
+        // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
+        const int g_row = lane >> 2, g_c4 = lane & 3;
+        auto load_luma = [&](int m) -> uint32_t {
+            const int fy = m / nx, fx = m - fy * nx;
+            return *(const uint32_t*)(frame + (size_t)(fy * 16 + g_row) * W + fx * 16 + g_c4 * 4);
+        };
+        auto load_chroma = [&](int m) -> uint32_t {
+            const int fy = m / nx, fx = m - fy * nx;
+            return *(const uint32_t*)(frame + (size_t)W * H + (size_t)(fy * 8 + (g_row & 7)) * W + fx * 16 + g_c4 * 4);
+        };
+        uint32_t yd = 0, cd = 0;
+        if (wid < nmb) {
+            yd = load_luma(wid);
+            cd = load_chroma(wid);     // lanes >= 32 re-read rows 0..7 (harmless, keeps the load unconditional)
+        }
+
         for (int m = wid; m < nmb; m += kWavesPerGroup) {
             const int fy = m / nx, fx = m - fy * nx;
             const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
 
-            // -- gather the macroblock's 384 source bytes (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
+            // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
             {
-                const int row = lane >> 2, c4 = lane & 3;
-                const uint8_t* yp = frame + (size_t)(fy * 16 + row) * W + fx * 16 + c4 * 4;
-                const uint32_t yd = *(const uint32_t*)yp;
-                const int blk = 2 + ((row >> 3) << 1) + (c4 >> 1);
-                pix32[(blk * 8 + (row & 7)) * 2 + (c4 & 1)] = yd;
+                const int blk = 2 + ((g_row >> 3) << 1) + (g_c4 >> 1);
+                pix32[(blk * 8 + (g_row & 7)) * 2 + (g_c4 & 1)] = yd;
                 if (lane < 32) {
-                    const uint8_t* cp = frame + (size_t)W * H + (size_t)(fy * 8 + row) * W + fx * 16 + c4 * 4;
-                    const uint32_t cd = *(const uint32_t*)cp;
                     const uint32_t cr = (cd & 0xFFu) | ((cd >> 8) & 0xFF00u);
                     const uint32_t cb = ((cd >> 8) & 0xFFu) | ((cd >> 16) & 0xFF00u);
-                    pix16[(0 * 8 + row) * 4 + c4] = (uint16_t)cr;
-                    pix16[(1 * 8 + row) * 4 + c4] = (uint16_t)cb;
+                    pix16[(0 * 8 + g_row) * 4 + g_c4] = (uint16_t)cr;
+                    pix16[(1 * 8 + g_row) * 4 + g_c4] = (uint16_t)cb;
                 }
             }
             wave_sync();
+            // -- prefetch the next macroblock of this wavefront while this one is transformed and counted
+            {
+                const int mn = m + kWavesPerGroup;
+                if (mn < nmb) {
+                    yd = load_luma(mn);
+                    cd = load_chroma(mn);
+                }
+            }
 
             const int blk = lane >> 3, r8 = lane & 7;
             int d[8];
@@ -367,7 +401,11 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
 
             if (lane == 0) {
 #pragma unroll
-                for (int b = 0; b < 6; b++) L.dcq[mbe * 6 + b] = (int16_t)quant_dc(coef[b]);
+                for (int b = 0; b < 6; b++) {
+                    const int dc = quant_dc(coef[b]);
+                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
+                    L.dcw[mbe * 6 + b] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                }
             }
 
             int acc[kScalesPerPass];
@@ -375,20 +413,28 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
 #pragma unroll
             for (int b = 0; b < 6; b++) {
-                const int a = coef[b] < 0 ? -coef[b] : coef[b];
-                const bool neg = coef[b] < 0;
+                const int c = lane == 0 ? 0 : coef[b];
+                const float two_abs = (float)(2 * (c < 0 ? -c : c));
+                const int lim = c < 0 ? 512 : 510;
 #pragma unroll
                 for (int s = 0; s < kScalesPerPass; s++) {
-                    uint64_t mask;
-                    int lvl, run;
-                    acc[s] += ac_block_bits(2 * a, neg, dq[s], inv[s], lc, L.ac_len, lane, mask, lvl, run);
+                    const AcEval e = ac_eval(two_abs, lim, inv[s], bias[s], lc);
+                    acc[s] += L.ac_len[e.idx];
                 }
             }
-#pragma unroll
-            for (int s = 0; s < kScalesPerPass; s++) {
-                const int t = wave::reduce_add(acc[s]);
-                wave_tot[s] += t;
-                if (lane == 0) L.mb_bits[mbe * kScalesPerPass + s] = (uint16_t)t;
+            // per-macroblock sums: two 16-bit counters per register (a macroblock's AC bits are < 2^14)
+            static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
+            const int t01 = wave::reduce_add(acc[0] | (acc[1] << 16));
+            const int t23 = wave::reduce_add(acc[2] | (acc[3] << 16));
+            wave_tot[0] += t01 & 0xFFFF;
+            wave_tot[1] += (unsigned)t01 >> 16;
+            wave_tot[2] += t23 & 0xFFFF;
+            wave_tot[3] += (unsigned)t23 >> 16;
+            if (lane == 0) {
+                uint2 v;
+                v.x = (uint32_t)t01;
+                v.y = (uint32_t)t23;
+                *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
             }
         }
         if (lane == 0) {
@@ -396,6 +442,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
         }
         __syncthreads();
+        clk.mark(1);
 
         // =====================================================================================
         // DC: v2 = 10 bits per block; v3 = DPCM chain per component in encode order (mdec.c:454-479)
@@ -415,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
                 const int i = base + lane;
                 const bool live = i < count;
                 const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
-                const int dc = live ? (int)L.dcq[idx] : 0;
+                const int dc = live ? (int)L.dcw[idx] : 0;
                 int thr, lo, hi;
                 if ((dc & 3) == 2) {
                     thr = dc; lo = dc + 2; hi = dc - 2;
@@ -445,9 +492,20 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
                     if (delta < -0x80) delta += 0x100;
                     else if (delta > 0x80) delta -= 0x100;
                 }
+                // the delta's VLC: size class = magnitude bits, then sign-dependent offset (mdec.c:285-318)
+                const int luma = wid == 2;
+                int dlen = luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
+                uint32_t dcode = luma ? BS_DC_LUMA_ZERO_CODE : BS_DC_CHROMA_ZERO_CODE;
+                if (delta != 0) {
+                    const int ad = delta < 0 ? -delta : delta;
+                    const int mm = 31 - __builtin_clz((unsigned)ad);
+                    const uint32_t j = delta > 0 ? (uint32_t)(delta - (1 << mm)) : (uint32_t)(delta + ((2 << mm) - 1));
+                    dlen = L.dc_plen[luma * 8 + mm] + 1 + mm;
+                    dcode = ((uint32_t)L.dc_prefix[luma * 8 + mm] << (mm + 1)) | ((delta > 0 ? 1u : 0u) << mm) | j;
+                }
                 if (live) {
-                    L.dcq[idx] = (int16_t)delta;
-                    bits += dc_delta_len(delta, wid == 2, L.dc_plen);
+                    L.dcw[idx] = ((uint32_t)dlen << 24) | dcode;
+                    bits += dlen;
                 }
                 carry = __shfl(cur, 63, 64);
                 if (base + 64 > count) break;
@@ -456,6 +514,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             if (lane == 0) atomicAdd(&L.scalars[0], bits);
         }
         __syncthreads();
+        clk.mark(2);
 
         // =====================================================================================
         // Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723)
@@ -486,31 +545,48 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < kScalesPerPass; s++) {
-                dq[s] = lc.quant * (scale0 + s);
-                inv[s] = 1.0f / (float)(2 * dq[s]);
+                inv[s] = 1.0f / (float)(2 * lc.quant * (scale0 + s));
+                bias[s] = 0.5f + 0.5f * inv[s];
                 wave_tot[s] = 0;
             }
+            int cn[6];
+            if (wid < nmb) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)wid * 384 + b * 64 + lane];
+            }
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                int cc[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) cc[b] = cn[b];
+                if (mbe + kWavesPerGroup < nmb) {
+#pragma unroll
+                    for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)(mbe + kWavesPerGroup) * 384 + b * 64 + lane];
+                }
                 int acc[kScalesPerPass];
 #pragma unroll
                 for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
-                    const int c = src[b * 64];
-                    const int a = c < 0 ? -c : c;
+                    const int c = lane == 0 ? 0 : cc[b];
+                    const float two_abs = (float)(2 * (c < 0 ? -c : c));
+                    const int lim = c < 0 ? 512 : 510;
 #pragma unroll
                     for (int s = 0; s < kScalesPerPass; s++) {
-                        uint64_t mask;
-                        int lvl, run;
-                        acc[s] += ac_block_bits(2 * a, c < 0, dq[s], inv[s], lc, L.ac_len, lane, mask, lvl, run);
+                        const AcEval e = ac_eval(two_abs, lim, inv[s], bias[s], lc);
+                        acc[s] += L.ac_len[e.idx];
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) {
-                    const int t = wave::reduce_add(acc[s]);
-                    wave_tot[s] += t;
-                    if (lane == 0) L.mb_bits[mbe * kScalesPerPass + s] = (uint16_t)t;
+                const int t01 = wave::reduce_add(acc[0] | (acc[1] << 16));
+                const int t23 = wave::reduce_add(acc[2] | (acc[3] << 16));
+                wave_tot[0] += t01 & 0xFFFF;
+                wave_tot[1] += (unsigned)t01 >> 16;
+                wave_tot[2] += t23 & 0xFFFF;
+                wave_tot[3] += (unsigned)t23 >> 16;
+                if (lane == 0) {
+                    uint2 v;
+                    v.x = (uint32_t)t01;
+                    v.y = (uint32_t)t23;
+                    *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
                 }
             }
             if (lane == 0) {
@@ -520,6 +596,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             __syncthreads();
         }
 
+        clk.mark(3);
         const int scale = L.scalars[1];
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
@@ -546,12 +623,8 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
                 int bits = 0;
                 if (mbe < nmb) {
                     bits = L.mb_bits[mbe * kScalesPerPass + sidx] + 12;   // six end-of-block codes
-                    if (CODEC == 0) {
-                        bits += 60;
-                    } else {
 #pragma unroll
-                        for (int b = 0; b < 6; b++) bits += dc_delta_len(L.dcq[mbe * 6 + b], b >= 2, L.dc_plen);
-                    }
+                    for (int b = 0; b < 6; b++) bits += (int)(L.dcw[mbe * 6 + b] >> 24);
                 }
                 const int incl = wave::inclusive_scan_add(bits);
                 if (mbe < nmb) L.mb_off[mbe] = carry + (uint32_t)(incl - bits);
@@ -559,68 +632,78 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             }
         }
         __syncthreads();
+        clk.mark(4);
 
         // =====================================================================================
-        // Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer
+        // Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer.
+        // Each block's 2-bit end-of-block code "10" (mdec.c:501-503) is written together with the NEXT
+        // block's DC code by lane 0 (one ds_or instead of two); the frame's last one goes out with the
+        // end-of-frame code below.
         // =====================================================================================
         {
             const int d1 = lc.quant * scale;
-            const float inv1 = 1.0f / (float)(2 * d1);
+            const float inv1 = 1.0f / (float)(2 * d1), bias1 = 0.5f + 0.5f * inv1;
             uint32_t* stream = L.out + 2;      // bitstream starts at byte 8 (mdec.c:686)
             int nnz = 0;
+            int cn[6];
+            if (wid < nmb) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)wid * 384 + b * 64 + lane];
+            }
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                int cc[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) cc[b] = cn[b];
+                if (mbe + kWavesPerGroup < nmb) {
+#pragma unroll
+                    for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)(mbe + kWavesPerGroup) * 384 + b * 64 + lane];
+                }
+                // all six blocks are evaluated first (independent chains the scheduler can interleave), then scanned,
+                // then written
+                int len[6], put_len[6], incl[6];
+                uint32_t code[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    const int c = lane == 0 ? 0 : cc[b];
+                    const bool neg = c < 0;
+                    const AcEval e = ac_eval((float)(2 * (neg ? -c : c)), neg ? 512 : 510, inv1, bias1, lc);
+                    const uint32_t entry = L.ac_code[e.idx];
+                    const int sl = neg ? -e.q : e.q;
+                    const uint32_t esc = (1u << 16) | ((uint32_t)e.run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
+                    int ln = (int)(entry >> 24);
+                    uint32_t cd_ = ln == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
+                    // lane 0: this block's DC code, preceded by the previous block's end-of-block code
+                    const uint32_t dcw = L.dcw[mbe * 6 + b];
+                    const bool fold = lane == 0 && (b > 0 || mbe > 0);
+                    if (lane == 0) {
+                        ln = (int)(dcw >> 24);
+                        cd_ = dcw & 0xFFFFFFu;
+                    }
+                    len[b] = ln;
+                    code[b] = fold ? (cd_ | (2u << ln)) : cd_;
+                    put_len[b] = fold ? ln + 2 : ln;
+                    nnz += (int)__builtin_popcountll(e.mask);
+                }
+#pragma unroll
+                for (int b = 0; b < 6; b++) incl[b] = wave::inclusive_scan_add(len[b]);
                 uint32_t pos = L.mb_off[mbe];
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
-                    const int c = src[b * 64];
-                    const int a = c < 0 ? -c : c;
-                    uint64_t mask;
-                    int lvl, run;
-                    int len = ac_block_bits(2 * a, c < 0, d1, inv1, lc, L.ac_len, lane, mask, lvl, run);
-                    uint32_t code = 0;
-                    if (len == BS_ESCAPE_BITS) {
-                        const int sl = c < 0 ? -lvl : lvl;
-                        code = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
-                    } else if (len) {
-                        code = (uint32_t)L.ac_code[run * BS_LUT_W + lvl] | (c < 0 ? 1u : 0u);
-                    }
-                    if (lane == 0) {
-                        // DC code (lane 0 never carries an AC code)
-                        const int dcv = L.dcq[mbe * 6 + b];
-                        if (CODEC == 0) {
-                            len = 10;
-                            code = (uint32_t)dcv & 0x3FFu;
-                        } else {
-                            const int luma = b >= 2;
-                            if (dcv == 0) {
-                                len = luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
-                                code = luma ? BS_DC_LUMA_ZERO_CODE : BS_DC_CHROMA_ZERO_CODE;
-                            } else {
-                                const int ad = dcv < 0 ? -dcv : dcv;
-                                const int mm = 31 - __builtin_clz((unsigned)ad);
-                                const uint32_t j = dcv > 0 ? (uint32_t)(dcv - (1 << mm)) : (uint32_t)(dcv + ((2 << mm) - 1));
-                                len = L.dc_plen[luma * 8 + mm] + 1 + mm;
-                                code = ((uint32_t)L.dc_prefix[luma * 8 + mm] << (mm + 1)) | ((dcv > 0 ? 1u : 0u) << mm) | j;
-                            }
-                        }
-                    }
-                    const int incl = wave::inclusive_scan_add(len);
-                    if (len) put_bits(stream, pos + (uint32_t)(incl - len), len, code);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                    if (lane == 63) put_bits(stream, pos + total, 2, 0x2u);   // end of block (mdec.c:501-503)
-                    pos += total + 2;
-                    nnz += (int)__builtin_popcountll(mask);
+                    const uint32_t at = pos + (uint32_t)(incl[b] - len[b]) - (uint32_t)(put_len[b] - len[b]);
+                    if (put_len[b]) put_bits(stream, at, put_len[b], code[b]);
+                    pos += (uint32_t)__builtin_amdgcn_readlane(incl[b], 63) + 2;
                 }
             }
             if (lane == 0) atomicAdd(&L.scalars[3], nnz);
         }
         __syncthreads();
+        clk.mark(5);
 
         // ---- end-of-frame code, header, results (mdec.c:710-754)
         const int total_bits = L.scalars[4];
         if (tid == 0) {
-            put_bits(L.out + 2, (uint32_t)(total_bits - 10), 10, CODEC == 0 ? 0x1FFu : 0x3FFu);
+            // last block's end-of-block code + end-of-frame code (mdec.c:647-651,710)
+            put_bits(L.out + 2, (uint32_t)(total_bits - 12), 12, (2u << 10) | (CODEC == 0 ? 0x1FFu : 0x3FFu));
             int hwords = L.scalars[3] + 2 * nblk + 2;
             hwords = (hwords + 0x3F) & ~0x3F;
             const int blocks_used = (hwords + 1) >> 1;
@@ -654,6 +737,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             }
         }
         __syncthreads();
+        clk.mark(6);
     }
 }
 
@@ -699,6 +783,7 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.results = a->d_results;
     job.coef_slab = a->d_coef_slab;
     job.out_words = a->out_words;
+    job.timing = a->d_timing;
     const size_t lds = lds_bytes(job.nmb, job.out_words);
     const dim3 grid((unsigned)a->grid), block(kThreads);
     hipStream_t st = (hipStream_t)a->stream;

@@ -73,6 +73,7 @@ struct psxhip_mdec_ctx {
     int groups_max;            // persistent grid size: compute units x resident groups per CU
     size_t lds_bytes;
     int16_t* d_slab;
+    unsigned long long* d_timing;   // diagnostics (PSXHIP_MDEC_TIMING=1)
     // host-path staging
     hipStream_t stream;
     uint8_t* d_frames;
@@ -124,6 +125,12 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     const size_t slab = psxhip_mdec_slab_bytes_per_group(c->nmb) * (size_t)c->groups_max;
     HIP_TRY(hipMalloc((void**)&c->d_slab, slab), PSXHIP_ENOMEM);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    if (const char* e = getenv("PSXHIP_MDEC_TIMING")) {
+        if (atoi(e)) {
+            HIP_TRY(hipMalloc((void**)&c->d_timing, 8 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
+            HIP_TRY(hipMemset(c->d_timing, 0, 8 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
+        }
+    }
     *out = c;
     return PSXHIP_OK;
 }
@@ -133,6 +140,7 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_slab) (void)hipFree(c->d_slab);
+    if (c->d_timing) (void)hipFree(c->d_timing);
     if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_res) (void)hipFree(c->d_res);
@@ -179,6 +187,7 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.out_words = c->out_words;
     a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
     a.stream = stream;
+    a.d_timing = c->d_timing;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
@@ -249,6 +258,17 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
                              frame_max_sizes ? frame_max_sizes[i] : uniform_max_size);
             return PSXHIP_ENOFIT;
         }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_read_timing(psxhip_mdec_ctx_t* c, unsigned long long* out8, int reset) {
+    if (!c || !out8) return PSXHIP_EINVAL;
+    memset(out8, 0, 8 * sizeof(unsigned long long));
+    if (!c->d_timing) return PSXHIP_OK;
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    HIP_TRY(hipDeviceSynchronize(), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpy(out8, c->d_timing, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
+    if (reset) HIP_TRY(hipMemset(c->d_timing, 0, 8 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
 

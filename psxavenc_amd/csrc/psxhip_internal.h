@@ -24,6 +24,7 @@ typedef struct {
 	int out_words;
 	int grid;
 	void *stream;
+	unsigned long long *d_timing;
 } psxhip_mdec_launch_t;
 
 size_t psxhip_mdec_lds_bytes(int nmb, int out_words);

@@ -58,9 +58,9 @@ def test_integer_form_of_divide_rounded():
 
 
 def test_fp32_reciprocal_quantiser_is_exact():
-    """The kernel computes floor(N / D) as trunc((float(N) + 0.5f) * rcp(D)), N = 2|n| + d, D = 2d.
-    Exhaustive over every divisor and every N the path can produce, with the reciprocal perturbed by +-2 ulp
-    (v_rcp_f32 is 1 ulp)."""
+    """The kernel computes floor(N / D) as trunc(fmaf(float(2|n|), r, 0.5f + 0.5f * r)), r = fp32(1 / D), N = 2|n| + d, D = 2d
+    (ac_eval() in mdec_kernels.hip; quant_level() documents the equivalent two-rounding form; all three forms are checked).  Exhaustive over every
+    divisor and every N the path can produce, with the reciprocal perturbed by +-2 ulp (v_rcp_f32 is 1 ulp)."""
     import sys
     sys.path.insert(0, os.path.join(O.ROOT, "tools"))
     import gen_tables as G
@@ -77,6 +77,14 @@ def test_fp32_reciprocal_quantiser_is_exact():
                 rr = np.nextafter(rr, np.float32(np.inf if ulps > 0 else -np.inf), dtype=np.float32)
             got = ((N.astype(np.float32) + np.float32(0.5)) * rr).astype(np.int64)
             assert np.array_equal(got, want), (d, ulps)
+            # fused form: exact product and sum in float64 (N < 2^18, r has 24 significant bits), one rounding to fp32
+            hr = np.float32(0.5) * rr
+            fused = (N.astype(np.float64) * np.float64(rr) + np.float64(hr)).astype(np.float32)
+            assert np.array_equal(fused.astype(np.int64), want), (d, ulps, "fma")
+            # the kernel's final form folds d / 2d = 0.5 into the addend: trunc(fmaf(float(2|n|), r, 0.5f + 0.5f * r))
+            bias = np.float32(0.5) + np.float32(0.5) * rr
+            folded = (a2.astype(np.float64) * np.float64(rr) + np.float64(bias)).astype(np.float32)
+            assert np.array_equal(folded.astype(np.int64), want), (d, ulps, "folded")
 
 
 def _levels_numpy(coefs, scale):
