@@ -32,7 +32,9 @@ namespace {
 constexpr int kWavesPerGroup = 16;
 constexpr int kThreads = kWavesPerGroup * 64;
 constexpr int kScalesPerPass = 4;
+constexpr int kWavesPerSimd = 8;    // occupancy target: two 16-wave workgroups (frames) per CU
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
+constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
 
 __constant__ uint8_t c_ac_len[BS_LUT_SIZE];
 __constant__ uint32_t c_ac_code[BS_LUT_SIZE];
@@ -160,7 +162,7 @@ struct Lds {
     int* scalars;           // [8]: 0 dc_bits, 1 chosen scale, 2 chosen index in pass, 3 nnz, 4 total bits
 };
 
-constexpr int kWaveTileBytes = 6 * kTileStride * 2 + 6 * 64 * 2;   // transpose tile + zig-zag tile (pixel tile aliases the latter)
+constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile (the pixel tile aliases the latter)
 
 __host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
     size_t b = 0;
@@ -240,8 +242,14 @@ __device__ __forceinline__ AcEval ac_eval(float two_abs_f, int lim, float inv2d,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register budget: the kernel is compiled for 8 wavefronts per SIMD (<= 64 VGPRs), i.e. two frames in
+// flight per CU.  The hot path is latency-bound (LDS look-ups, DPP scans, ballots), so it is written
+// as short per-block bodies that rely on 8-way wave interleaving rather than on wide unrolled bodies
+// that would need > 64 registers.  The three per-macroblock loops are: (A) DCT -> slab, (B) bit counts
+// for kScalesPerPass scales from the slab, (C) emit at the chosen scale from the slab.
+// ---------------------------------------------------------------------------------------------
 template <int CODEC>
-__global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const FrameJob job) {
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_kernel(const FrameJob job) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds L = carve(smem, job.nmb, job.out_words);
 
@@ -265,21 +273,23 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
     lc.below = (1ull << lane) - 1ull;
     lc.lane_m64 = lane - 64;
 
-    // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3)
-    int zpos[8];
+    // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3);
+    // the eight scan positions are packed one byte each into two registers
+    uint32_t zpos_lo = 0, zpos_hi = 0;
     {
-        // raster position -> scan position, built from the scan table
-        // (64 lanes: lane k knows c_zagzig[k]; invert through LDS once)
         uint8_t* inv = (uint8_t*)L.tiles;   // temporary use before the tiles are live
         if (tid < 64) inv[c_zagzig[tid]] = (uint8_t)tid;
         __syncthreads();
 #pragma unroll
-        for (int v = 0; v < 8; v++) zpos[v] = inv[v * 8 + (lane & 7)];
+        for (int v = 0; v < 4; v++) {
+            zpos_lo |= (uint32_t)inv[v * 8 + (lane & 7)] << (8 * v);
+            zpos_hi |= (uint32_t)inv[(v + 4) * 8 + (lane & 7)] << (8 * v);
+        }
         __syncthreads();
     }
 
     int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
-    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][64] zig-zag ordered coefficients
+    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
     uint32_t* pix32 = (uint32_t*)tileZ;                                // [6][8][2] dwords of source pixels (aliases tileZ)
     uint16_t* pix16 = (uint16_t*)tileZ;
 
@@ -301,145 +311,97 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
         clk.mark(0);
 
         // =====================================================================================
-        // Pass 1: DCT of every macroblock + AC bit counts for scales 1..kScalesPerPass
+        // (A) DCT of every macroblock -> coefficient slab (zig-zag order) + quantised DC
         // =====================================================================================
-        float inv[kScalesPerPass], bias[kScalesPerPass];
-#pragma unroll
-        for (int s = 0; s < kScalesPerPass; s++) {
-            inv[s] = 1.0f / (float)(2 * lc.quant * (1 + s));
-            bias[s] = 0.5f + 0.5f * inv[s];
-        }
-        int wave_tot[kScalesPerPass];
-#pragma unroll
-        for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
+        {
+            // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
+            const int g_row = lane >> 2, g_c4 = lane & 3;
+            const uint8_t* luma0 = frame + (size_t)g_row * W + g_c4 * 4;
+            const uint8_t* chroma0 = frame + (size_t)W * H + (size_t)(g_row & 7) * W + g_c4 * 4;
+            uint32_t yd = 0, cd = 0;
+            if (wid < nmb) {
+                const int fy = wid / nx, fx = wid - fy * nx;
+                yd = *(const uint32_t*)(luma0 + (size_t)fy * 16 * W + fx * 16);
+                cd = *(const uint32_t*)(chroma0 + (size_t)fy * 8 * W + fx * 16);   // lanes >= 32 re-read rows 0..7 (unused)
+            }
+            for (int m = wid; m < nmb; m += kWavesPerGroup) {
+                const int fy = m / nx, fx = m - fy * nx;
+                const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
 
-        // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
-        const int g_row = lane >> 2, g_c4 = lane & 3;
-        auto load_luma = [&](int m) -> uint32_t {
-            const int fy = m / nx, fx = m - fy * nx;
-            return *(const uint32_t*)(frame + (size_t)(fy * 16 + g_row) * W + fx * 16 + g_c4 * 4);
-        };
-        auto load_chroma = [&](int m) -> uint32_t {
-            const int fy = m / nx, fx = m - fy * nx;
-            return *(const uint32_t*)(frame + (size_t)W * H + (size_t)(fy * 8 + (g_row & 7)) * W + fx * 16 + g_c4 * 4);
-        };
-        uint32_t yd = 0, cd = 0;
-        if (wid < nmb) {
-            yd = load_luma(wid);
-            cd = load_chroma(wid);     // lanes >= 32 re-read rows 0..7 (harmless, keeps the load unconditional)
-        }
-
-        for (int m = wid; m < nmb; m += kWavesPerGroup) {
-            const int fy = m / nx, fx = m - fy * nx;
-            const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
-
-            // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
-            {
-                const int blk = 2 + ((g_row >> 3) << 1) + (g_c4 >> 1);
-                pix32[(blk * 8 + (g_row & 7)) * 2 + (g_c4 & 1)] = yd;
-                if (lane < 32) {
-                    const uint32_t cr = (cd & 0xFFu) | ((cd >> 8) & 0xFF00u);
-                    const uint32_t cb = ((cd >> 8) & 0xFFu) | ((cd >> 16) & 0xFF00u);
-                    pix16[(0 * 8 + g_row) * 4 + g_c4] = (uint16_t)cr;
-                    pix16[(1 * 8 + g_row) * 4 + g_c4] = (uint16_t)cb;
+                // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
+                {
+                    const int blk = 2 + ((g_row >> 3) << 1) + (g_c4 >> 1);
+                    pix32[(blk * 8 + (g_row & 7)) * 2 + (g_c4 & 1)] = yd;
+                    if (lane < 32) {
+                        const uint32_t cr = (cd & 0xFFu) | ((cd >> 8) & 0xFF00u);
+                        const uint32_t cb = ((cd >> 8) & 0xFFu) | ((cd >> 16) & 0xFF00u);
+                        pix16[(0 * 8 + g_row) * 4 + g_c4] = (uint16_t)cr;
+                        pix16[(1 * 8 + g_row) * 4 + g_c4] = (uint16_t)cb;
+                    }
                 }
-            }
-            wave_sync();
-            // -- prefetch the next macroblock of this wavefront while this one is transformed and counted
-            {
-                const int mn = m + kWavesPerGroup;
-                if (mn < nmb) {
-                    yd = load_luma(mn);
-                    cd = load_chroma(mn);
+                wave_sync();
+                // -- prefetch the next macroblock of this wavefront while this one is transformed
+                {
+                    const int mn = m + kWavesPerGroup;
+                    if (mn < nmb) {
+                        const int fyn = mn / nx, fxn = mn - fyn * nx;
+                        yd = *(const uint32_t*)(luma0 + (size_t)fyn * 16 * W + fxn * 16);
+                        cd = *(const uint32_t*)(chroma0 + (size_t)fyn * 8 * W + fxn * 16);
+                    }
                 }
-            }
 
-            const int blk = lane >> 3, r8 = lane & 7;
-            int d[8];
-            if (lane < 48) {
-                // -- row pass: lane = (block, row)
-                const uint2 p = *(const uint2*)&pix32[(blk * 8 + r8) * 2];
-                d[0] = (int)(p.x & 0xFF) - 128;
-                d[1] = (int)((p.x >> 8) & 0xFF) - 128;
-                d[2] = (int)((p.x >> 16) & 0xFF) - 128;
-                d[3] = (int)(p.x >> 24) - 128;
-                d[4] = (int)(p.y & 0xFF) - 128;
-                d[5] = (int)((p.y >> 8) & 0xFF) - 128;
-                d[6] = (int)((p.y >> 16) & 0xFF) - 128;
-                d[7] = (int)(p.y >> 24) - 128;
-                fdct8<false>(d);
+                const int blk = lane >> 3, r8 = lane & 7;
+                int d[8];
+                if (lane < 48) {
+                    // -- row pass: lane = (block, row)
+                    const uint2 p = *(const uint2*)&pix32[(blk * 8 + r8) * 2];
+                    d[0] = (int)(p.x & 0xFF) - 128;
+                    d[1] = (int)((p.x >> 8) & 0xFF) - 128;
+                    d[2] = (int)((p.x >> 16) & 0xFF) - 128;
+                    d[3] = (int)(p.x >> 24) - 128;
+                    d[4] = (int)(p.y & 0xFF) - 128;
+                    d[5] = (int)((p.y >> 8) & 0xFF) - 128;
+                    d[6] = (int)((p.y >> 16) & 0xFF) - 128;
+                    d[7] = (int)(p.y >> 24) - 128;
+                    fdct8<false>(d);
 #pragma unroll
-                for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
-            }
-            wave_sync();
-            if (lane < 48) {
-                // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
-                const int4 q = *(const int4*)&tileT[blk * kTileStride + r8 * 8];
-                d[0] = (int)(int16_t)(q.x & 0xFFFF);
-                d[1] = q.x >> 16;
-                d[2] = (int)(int16_t)(q.y & 0xFFFF);
-                d[3] = q.y >> 16;
-                d[4] = (int)(int16_t)(q.z & 0xFFFF);
-                d[5] = q.z >> 16;
-                d[6] = (int)(int16_t)(q.w & 0xFFFF);
-                d[7] = q.w >> 16;
-                fdct8<true>(d);
+                    for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+                }
+                wave_sync();
+                if (lane < 48) {
+                    // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
+                    const int4 q = *(const int4*)&tileT[blk * kTileStride + r8 * 8];
+                    d[0] = (int)(int16_t)(q.x & 0xFFFF);
+                    d[1] = q.x >> 16;
+                    d[2] = (int)(int16_t)(q.y & 0xFFFF);
+                    d[3] = q.y >> 16;
+                    d[4] = (int)(int16_t)(q.z & 0xFFFF);
+                    d[5] = q.z >> 16;
+                    d[6] = (int)(int16_t)(q.w & 0xFFFF);
+                    d[7] = q.w >> 16;
+                    fdct8<true>(d);
 #pragma unroll
-                for (int v = 0; v < 8; v++) tileZ[blk * 64 + zpos[v]] = (int16_t)d[v];
-            }
-            wave_sync();
+                    for (int v = 0; v < 8; v++) {
+                        const uint32_t zp = ((v < 4 ? zpos_lo : zpos_hi) >> (8 * (v & 3))) & 0xFFu;
+                        tileZ[blk * kZStride + zp] = (int16_t)d[v];
+                    }
+                }
+                wave_sync();
 
-            // -- lane k now owns zig-zag position k of each of the 6 blocks
-            int coef[6];
-#pragma unroll
-            for (int b = 0; b < 6; b++) coef[b] = tileZ[b * 64 + lane];
-            wave_sync();   // tileZ is the next iteration's pixel tile
-
-            int16_t* dst = slab + (size_t)mbe * 384 + lane;
-#pragma unroll
-            for (int b = 0; b < 6; b++) dst[b * 64] = (int16_t)coef[b];
-
-            if (lane == 0) {
+                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, DC to LDS
+                int16_t* dst = slab + (size_t)mbe * 384 + lane;
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
-                    const int dc = quant_dc(coef[b]);
-                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
-                    L.dcw[mbe * 6 + b] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                    const int c = tileZ[b * kZStride + lane];
+                    dst[b * 64] = (int16_t)c;
+                    if (lane == 0) {
+                        const int dc = quant_dc(c);
+                        // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
+                        L.dcw[mbe * 6 + b] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                    }
                 }
+                wave_sync();   // tileZ is the next iteration's pixel tile
             }
-
-            int acc[kScalesPerPass];
-#pragma unroll
-            for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                const int c = lane == 0 ? 0 : coef[b];
-                const float two_abs = (float)(2 * (c < 0 ? -c : c));
-                const int lim = c < 0 ? 512 : 510;
-#pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) {
-                    const AcEval e = ac_eval(two_abs, lim, inv[s], bias[s], lc);
-                    acc[s] += L.ac_len[e.idx];
-                }
-            }
-            // per-macroblock sums: two 16-bit counters per register (a macroblock's AC bits are < 2^14)
-            static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
-            const int t01 = wave::reduce_add(acc[0] | (acc[1] << 16));
-            const int t23 = wave::reduce_add(acc[2] | (acc[3] << 16));
-            wave_tot[0] += t01 & 0xFFFF;
-            wave_tot[1] += (unsigned)t01 >> 16;
-            wave_tot[2] += t23 & 0xFFFF;
-            wave_tot[3] += (unsigned)t23 >> 16;
-            if (lane == 0) {
-                uint2 v;
-                v.x = (uint32_t)t01;
-                v.y = (uint32_t)t23;
-                *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
         }
         __syncthreads();
         clk.mark(1);
@@ -471,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
                     const int rq = ((a + 2) >> 2) << 2;
                     thr = 0; lo = hi = dc < 0 ? -rq : rq;
                 }
-                if (!live) { thr = -100000; lo = hi = 0; }   // identity is never needed: dead lanes sit after all live ones
+                if (!live) { thr = -100000; lo = hi = 0; }   // dead lanes sit after all live ones, never feed them
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const int pthr = __shfl_up(thr, off, 64);
@@ -508,7 +470,6 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
                     bits += dlen;
                 }
                 carry = __shfl(cur, 63, 64);
-                if (base + 64 > count) break;
             }
             bits = wave::reduce_add(bits);
             if (lane == 0) atomicAdd(&L.scalars[0], bits);
@@ -517,10 +478,60 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
         clk.mark(2);
 
         // =====================================================================================
-        // Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723)
+        // (B) Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723),
+        //     kScalesPerPass scales per pass over the slab
         // =====================================================================================
         int scale0 = 1;   // first scale of the current pass
         for (;;) {
+            {
+                float inv[kScalesPerPass], bias[kScalesPerPass];
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) {
+                    inv[s] = 1.0f / (float)(2 * lc.quant * (scale0 + s));
+                    bias[s] = 0.5f + 0.5f * inv[s];
+                }
+                int wave_tot[kScalesPerPass];
+#pragma unroll
+                for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
+
+                for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
+                    const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                    int acc01 = 0, acc23 = 0;      // two 16-bit counters per register (a macroblock's AC bits are < 2^14)
+                    int cnext = src[0];
+#pragma unroll 1
+                    for (int b = 0; b < 6; b++) {
+                        int c = lane == 0 ? 0 : cnext;
+                        if (b < 5) cnext = src[(b + 1) * 64];
+                        const float two_abs = (float)(2 * (c < 0 ? -c : c));
+                        const int lim = c < 0 ? 512 : 510;
+                        static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
+                        const AcEval e0 = ac_eval(two_abs, lim, inv[0], bias[0], lc);
+                        const AcEval e1 = ac_eval(two_abs, lim, inv[1], bias[1], lc);
+                        const AcEval e2 = ac_eval(two_abs, lim, inv[2], bias[2], lc);
+                        const AcEval e3 = ac_eval(two_abs, lim, inv[3], bias[3], lc);
+                        acc01 += (int)L.ac_len[e0.idx] | ((int)L.ac_len[e1.idx] << 16);
+                        acc23 += (int)L.ac_len[e2.idx] | ((int)L.ac_len[e3.idx] << 16);
+                    }
+                    const int t01 = wave::reduce_add(acc01);
+                    const int t23 = wave::reduce_add(acc23);
+                    wave_tot[0] += t01 & 0xFFFF;
+                    wave_tot[1] += (unsigned)t01 >> 16;
+                    wave_tot[2] += t23 & 0xFFFF;
+                    wave_tot[3] += (unsigned)t23 >> 16;
+                    if (lane == 0) {
+                        uint2 v;
+                        v.x = (uint32_t)t01;
+                        v.y = (uint32_t)t23;
+                        *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
+                }
+            }
+            __syncthreads();
+
             if (tid == 0) {
                 const int fixed = L.scalars[0] + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
                 int chosen = 0;
@@ -538,65 +549,12 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
             __syncthreads();
             if (L.scalars[1] != 0 || scale0 + kScalesPerPass >= 64) break;
             __syncthreads();
-
-            // ---- next pass: scales scale0+K .. scale0+2K-1 from the coefficient slab
             scale0 += kScalesPerPass;
             if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
             __syncthreads();
-#pragma unroll
-            for (int s = 0; s < kScalesPerPass; s++) {
-                inv[s] = 1.0f / (float)(2 * lc.quant * (scale0 + s));
-                bias[s] = 0.5f + 0.5f * inv[s];
-                wave_tot[s] = 0;
-            }
-            int cn[6];
-            if (wid < nmb) {
-#pragma unroll
-                for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)wid * 384 + b * 64 + lane];
-            }
-            for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                int cc[6];
-#pragma unroll
-                for (int b = 0; b < 6; b++) cc[b] = cn[b];
-                if (mbe + kWavesPerGroup < nmb) {
-#pragma unroll
-                    for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)(mbe + kWavesPerGroup) * 384 + b * 64 + lane];
-                }
-                int acc[kScalesPerPass];
-#pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) acc[s] = 0;
-#pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    const int c = lane == 0 ? 0 : cc[b];
-                    const float two_abs = (float)(2 * (c < 0 ? -c : c));
-                    const int lim = c < 0 ? 512 : 510;
-#pragma unroll
-                    for (int s = 0; s < kScalesPerPass; s++) {
-                        const AcEval e = ac_eval(two_abs, lim, inv[s], bias[s], lc);
-                        acc[s] += L.ac_len[e.idx];
-                    }
-                }
-                const int t01 = wave::reduce_add(acc[0] | (acc[1] << 16));
-                const int t23 = wave::reduce_add(acc[2] | (acc[3] << 16));
-                wave_tot[0] += t01 & 0xFFFF;
-                wave_tot[1] += (unsigned)t01 >> 16;
-                wave_tot[2] += t23 & 0xFFFF;
-                wave_tot[3] += (unsigned)t23 >> 16;
-                if (lane == 0) {
-                    uint2 v;
-                    v.x = (uint32_t)t01;
-                    v.y = (uint32_t)t23;
-                    *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
-            }
-            __syncthreads();
         }
-
         clk.mark(3);
+
         const int scale = L.scalars[1];
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
@@ -635,63 +593,46 @@ __global__ __launch_bounds__(kThreads) void mdec_encode_frames_kernel(const Fram
         clk.mark(4);
 
         // =====================================================================================
-        // Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer.
+        // (C) Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer.
         // Each block's 2-bit end-of-block code "10" (mdec.c:501-503) is written together with the NEXT
         // block's DC code by lane 0 (one ds_or instead of two); the frame's last one goes out with the
         // end-of-frame code below.
         // =====================================================================================
         {
-            const int d1 = lc.quant * scale;
-            const float inv1 = 1.0f / (float)(2 * d1), bias1 = 0.5f + 0.5f * inv1;
+            const float inv1 = 1.0f / (float)(2 * lc.quant * scale), bias1 = 0.5f + 0.5f * inv1;
             uint32_t* stream = L.out + 2;      // bitstream starts at byte 8 (mdec.c:686)
             int nnz = 0;
-            int cn[6];
-            if (wid < nmb) {
-#pragma unroll
-                for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)wid * 384 + b * 64 + lane];
-            }
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                int cc[6];
-#pragma unroll
-                for (int b = 0; b < 6; b++) cc[b] = cn[b];
-                if (mbe + kWavesPerGroup < nmb) {
-#pragma unroll
-                    for (int b = 0; b < 6; b++) cn[b] = slab[(size_t)(mbe + kWavesPerGroup) * 384 + b * 64 + lane];
-                }
-                // all six blocks are evaluated first (independent chains the scheduler can interleave), then scanned,
-                // then written
-                int len[6], put_len[6], incl[6];
-                uint32_t code[6];
-#pragma unroll
+                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                uint32_t pos = L.mb_off[mbe];
+                int cnext = src[0];
+#pragma unroll 1
                 for (int b = 0; b < 6; b++) {
-                    const int c = lane == 0 ? 0 : cc[b];
+                    const int c = lane == 0 ? 0 : cnext;
+                    if (b < 5) cnext = src[(b + 1) * 64];
                     const bool neg = c < 0;
                     const AcEval e = ac_eval((float)(2 * (neg ? -c : c)), neg ? 512 : 510, inv1, bias1, lc);
                     const uint32_t entry = L.ac_code[e.idx];
                     const int sl = neg ? -e.q : e.q;
                     const uint32_t esc = (1u << 16) | ((uint32_t)e.run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
-                    int ln = (int)(entry >> 24);
-                    uint32_t cd_ = ln == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
+                    int len = (int)(entry >> 24);
+                    uint32_t code = len == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
                     // lane 0: this block's DC code, preceded by the previous block's end-of-block code
                     const uint32_t dcw = L.dcw[mbe * 6 + b];
-                    const bool fold = lane == 0 && (b > 0 || mbe > 0);
+                    int put_len = len;
                     if (lane == 0) {
-                        ln = (int)(dcw >> 24);
-                        cd_ = dcw & 0xFFFFFFu;
+                        len = (int)(dcw >> 24);
+                        code = dcw & 0xFFFFFFu;
+                        put_len = len;
+                        if (b > 0 || mbe > 0) {
+                            code |= 2u << len;
+                            put_len = len + 2;
+                        }
                     }
-                    len[b] = ln;
-                    code[b] = fold ? (cd_ | (2u << ln)) : cd_;
-                    put_len[b] = fold ? ln + 2 : ln;
+                    const int incl = wave::inclusive_scan_add(len);
+                    if (put_len) put_bits(stream, pos + (uint32_t)(incl - put_len), put_len, code);
+                    pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63) + 2;
                     nnz += (int)__builtin_popcountll(e.mask);
-                }
-#pragma unroll
-                for (int b = 0; b < 6; b++) incl[b] = wave::inclusive_scan_add(len[b]);
-                uint32_t pos = L.mb_off[mbe];
-#pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    const uint32_t at = pos + (uint32_t)(incl[b] - len[b]) - (uint32_t)(put_len[b] - len[b]);
-                    if (put_len[b]) put_bits(stream, at, put_len[b], code[b]);
-                    pos += (uint32_t)__builtin_amdgcn_readlane(incl[b], 63) + 2;
                 }
             }
             if (lane == 0) atomicAdd(&L.scalars[3], nnz);
