@@ -215,30 +215,28 @@ struct LaneConst {
     int lane_m64;       // lane - 64
 };
 
-// One block at one scale, branch-free: quantised magnitude `q`, run of zeros before this lane, and the
-// index of (run, q) in the padded LUTs (level 0 -> column 0 -> 0 bits, so silent lanes need no predicate).
-// `two_abs_f` = float(2|n|), 0 on lane 0 (the DC slot never carries an AC code); `lim` = 512 for negative
-// coefficients, 510 for positive ones (clamp range, mdec.c:260-267); `inv2d` = 1/(2 quant scale),
-// `bias` = 0.5 + 0.5 * inv2d.
-struct AcEval {
-    uint64_t mask;   // ballot of non-zero levels (bit 0 never set)
-    int q, run, idx;
-};
-__device__ __forceinline__ AcEval ac_eval(float two_abs_f, int lim, float inv2d, float bias, const LaneConst& lc) {
-    AcEval e;
-    // floor((2|n| + d) / 2d) with d / 2d = 0.5 folded into the addend: trunc(fma(2|n|, 1/2d, 0.5 + 0.5/2d)).
-    // Same argument as quant_level(): the exact value is >= 0.5/2d away from every integer, the computed one
-    // is within (2|n| + d) * 1.5 * 2^-23 / 2d + 2^-25 of it (tests/test_mdec_oracle.py checks every operand).
-    int q = (int)__builtin_fmaf(two_abs_f, inv2d, bias);
-    q = q > lim ? lim : q;
-    e.mask = wave::ballot(q != 0);
-    const uint64_t prev = (e.mask | 1ull) & lc.below;      // bit 0 = the DC slot, the "previous coefficient" sentinel
-    e.run = __clzll((long long)prev) + lc.lane_m64;        // lane - 1 - (63 - clz)
-    e.q = q;
-    const int rc = e.run > BS_LUT_MAX_RUN + 1 ? BS_LUT_MAX_RUN + 1 : e.run;
+// One block at one scale, branch-free.  `two_abs_f` = float(2|n|), 0 on lane 0 (the DC slot never carries an
+// AC code); `inv2d` = 1/(2 quant scale), `bias` = 0.5 + 0.5 * inv2d.
+//   floor((2|n| + d) / 2d) with d / 2d = 0.5 folded into the addend: trunc(fma(2|n|, 1/2d, 0.5 + 0.5/2d)).
+//   Same argument as quant_level(): the exact value is >= 0.5/2d away from every integer, the computed one is
+//   within (2|n| + d) * 1.5 * 2^-23 / 2d + 2^-25 of it (tests/test_mdec_oracle.py checks every operand).
+__device__ __forceinline__ int quant_mag(float two_abs_f, float inv2d, float bias) {
+    return (int)__builtin_fmaf(two_abs_f, inv2d, bias);
+}
+
+// number of zero coefficients between this lane and the previous non-zero one (bit 0 of the mask, the
+// DC slot, is the sentinel): lane - 1 - (63 - clz(mask below me))
+__device__ __forceinline__ int run_before(uint64_t nz_mask, const LaneConst& lc) {
+    const uint64_t prev = (nz_mask | 1ull) & lc.below;
+    return __clzll((long long)prev) + lc.lane_m64;
+}
+
+// index into the padded LUTs: row = min(|level|, MAX_LEVEL + 1), column = run (0..62).  Level 0 is row 0
+// = 0 bits, so silent lanes need no predicate.  Only the LENGTH needs no level clamp at 510/512
+// (mdec.c:260-267): every level > MAX_LEVEL is an escape of the same length.
+__device__ __forceinline__ int lut_index(int q, int run) {
     const int qc = q > BS_LUT_MAX_LEVEL + 1 ? BS_LUT_MAX_LEVEL + 1 : q;
-    e.idx = rc * BS_LUT_W + qc;
-    return e;
+    return qc * BS_LUT_W + run;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -503,14 +501,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                         int c = lane == 0 ? 0 : cnext;
                         if (b < 5) cnext = src[(b + 1) * 64];
                         const float two_abs = (float)(2 * (c < 0 ? -c : c));
-                        const int lim = c < 0 ? 512 : 510;
                         static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
-                        const AcEval e0 = ac_eval(two_abs, lim, inv[0], bias[0], lc);
-                        const AcEval e1 = ac_eval(two_abs, lim, inv[1], bias[1], lc);
-                        const AcEval e2 = ac_eval(two_abs, lim, inv[2], bias[2], lc);
-                        const AcEval e3 = ac_eval(two_abs, lim, inv[3], bias[3], lc);
-                        acc01 += (int)L.ac_len[e0.idx] | ((int)L.ac_len[e1.idx] << 16);
-                        acc23 += (int)L.ac_len[e2.idx] | ((int)L.ac_len[e3.idx] << 16);
+                        const int q0 = quant_mag(two_abs, inv[0], bias[0]);
+                        const int q1 = quant_mag(two_abs, inv[1], bias[1]);
+                        const int q2 = quant_mag(two_abs, inv[2], bias[2]);
+                        const int q3 = quant_mag(two_abs, inv[3], bias[3]);
+                        const int i0 = lut_index(q0, run_before(wave::ballot(q0 != 0), lc));
+                        const int i1 = lut_index(q1, run_before(wave::ballot(q1 != 0), lc));
+                        const int i2 = lut_index(q2, run_before(wave::ballot(q2 != 0), lc));
+                        const int i3 = lut_index(q3, run_before(wave::ballot(q3 != 0), lc));
+                        acc01 += (int)L.ac_len[i0] | ((int)L.ac_len[i1] << 16);
+                        acc23 += (int)L.ac_len[i2] | ((int)L.ac_len[i3] << 16);
                     }
                     const int t01 = wave::reduce_add(acc01);
                     const int t23 = wave::reduce_add(acc23);
@@ -593,47 +594,81 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         clk.mark(4);
 
         // =====================================================================================
-        // (C) Emit: quantise at the chosen scale, VLC, pack into the LDS staging buffer.
-        // Each block's 2-bit end-of-block code "10" (mdec.c:501-503) is written together with the NEXT
-        // block's DC code by lane 0 (one ds_or instead of two); the frame's last one goes out with the
-        // end-of-frame code below.
+        // (C) Emit at the chosen scale.  At the accepted scale only a few of a block's 64 coefficients are
+        // non-zero, so the expensive part (VLC look-up, bit positions, LDS writes) runs on a COMPACTED list:
+        //   1. per block: quantise, ballot, and append {level, sign, scan position} of the non-zero lanes to a
+        //      per-wavefront list in LDS.  Lane 0 always appends the block's DC slot, so the list is exactly
+        //      the macroblock's code sequence: DC, AC..., DC, AC..., and the run before an AC coefficient is
+        //      simply (its position - its predecessor's position - 1);
+        //   2. per 64 list entries: look the codes up, prefix-sum their lengths, OR them into the frame image.
+        // Each block's 2-bit end-of-block code "10" (mdec.c:501-503) travels as two extra leading bits of the
+        // NEXT block's DC code; the frame's last one goes out with the end-of-frame code below.
         // =====================================================================================
         {
             const float inv1 = 1.0f / (float)(2 * lc.quant * scale), bias1 = 0.5f + 0.5f * inv1;
-            uint32_t* stream = L.out + 2;      // bitstream starts at byte 8 (mdec.c:686)
+            uint32_t* stream = L.out + 2;                  // bitstream starts at byte 8 (mdec.c:686)
+            uint32_t* clist = (uint32_t*)tileT;            // the DCT tiles are idle now: 384 entries fit (kWaveTileBytes >= 1536)
+            const uint32_t lane_tag = (uint32_t)lane << 11;
             int nnz = 0;
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
                 const int16_t* src = slab + (size_t)mbe * 384 + lane;
-                uint32_t pos = L.mb_off[mbe];
+                // ---- 1. compaction
+                int count = 0;                             // wave-uniform
                 int cnext = src[0];
 #pragma unroll 1
                 for (int b = 0; b < 6; b++) {
-                    const int c = lane == 0 ? 0 : cnext;
+                    const int c = cnext;
                     if (b < 5) cnext = src[(b + 1) * 64];
                     const bool neg = c < 0;
-                    const AcEval e = ac_eval((float)(2 * (neg ? -c : c)), neg ? 512 : 510, inv1, bias1, lc);
-                    const uint32_t entry = L.ac_code[e.idx];
-                    const int sl = neg ? -e.q : e.q;
-                    const uint32_t esc = (1u << 16) | ((uint32_t)e.run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
+                    int q = quant_mag((float)(2 * (neg ? -c : c)), inv1, bias1);
+                    const int lim = neg ? 512 : 510;       // level clamp, mdec.c:260-267
+                    q = q > lim ? lim : q;
+                    const bool keep = lane == 0 || q != 0;
+                    const uint64_t m = wave::ballot(keep);
+                    if (keep) {
+                        // [9:0] |level| (lane 0: block index), [10] sign, [16:11] scan position
+                        const uint32_t payload = lane == 0 ? (uint32_t)b : ((uint32_t)q | (neg ? 0x400u : 0u));
+                        clist[count + wave::popc_below(m)] = payload | lane_tag;
+                    }
+                    const int n = (int)__builtin_popcountll(m);
+                    count += n;
+                    nnz += n - 1;
+                }
+                wave_sync();
+
+                // ---- 2. codes
+                uint32_t pos = L.mb_off[mbe] - (mbe > 0 ? 2u : 0u);   // the previous macroblock's last end-of-block code starts here
+                int kcarry = 0;
+                for (int base = 0; base < count; base += 64) {
+                    const int i = base + lane;
+                    const bool live = i < count;
+                    const uint32_t e = live ? clist[i] : 0u;
+                    const int k = (int)(e >> 11);
+                    const int q = (int)(e & 0x3FFu);
+                    const bool neg = (e & 0x400u) != 0;
+                    const bool is_dc = k == 0;
+                    int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                    const int run = is_dc ? 0 : k - kprev - 1;
+                    const uint32_t entry = L.ac_code[lut_index(is_dc ? 0 : q, run)];
+                    const int sl = neg ? -q : q;
+                    const uint32_t esc = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
                     int len = (int)(entry >> 24);
                     uint32_t code = len == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
-                    // lane 0: this block's DC code, preceded by the previous block's end-of-block code
-                    const uint32_t dcw = L.dcw[mbe * 6 + b];
-                    int put_len = len;
-                    if (lane == 0) {
+                    if (is_dc && live) {
+                        const uint32_t dcw = L.dcw[mbe * 6 + q];      // q holds the block index for DC entries
                         len = (int)(dcw >> 24);
                         code = dcw & 0xFFFFFFu;
-                        put_len = len;
-                        if (b > 0 || mbe > 0) {
+                        if (q > 0 || mbe > 0) {                        // carry the previous block's end-of-block code
                             code |= 2u << len;
-                            put_len = len + 2;
+                            len += 2;
                         }
                     }
                     const int incl = wave::inclusive_scan_add(len);
-                    if (put_len) put_bits(stream, pos + (uint32_t)(incl - put_len), put_len, code);
-                    pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63) + 2;
-                    nnz += (int)__builtin_popcountll(e.mask);
+                    if (len) put_bits(stream, pos + (uint32_t)(incl - len), len, code);
+                    pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                    kcarry = __builtin_amdgcn_readlane(k, 63);
                 }
+                wave_sync();   // the list is rewritten by the next macroblock
             }
             if (lane == 0) atomicAdd(&L.scalars[3], nnz);
         }
