@@ -109,6 +109,19 @@ int psxhip_adpcm_encode_chains_device(int device, const int16_t *d_samples, cons
                                       const int32_t *d_unit_base, int n_chains, int filter_count, int bits,
                                       psxhip_adpcm_state_t *d_states, uint8_t *d_units, void *stream);
 
+/* Same result as psxhip_adpcm_encode_chains_device, but parallel ALONG each chain ("speculate and verify"):
+ * chains are cut into chunks of `chunk_units` sound units, every chunk is encoded concurrently from a guessed
+ * start state (obtained by running `warmup_units` units before the chunk from a zero state), then verify
+ * passes re-encode any chunk whose guess differs from its predecessor's actual end state, until a pass changes
+ * nothing.  The fixpoint equals the serial encode bit for bit; the guesses only affect speed.  `chains` and
+ * `unit_base` are HOST arrays here (the chunk tables are built on the host); the call synchronises.
+ * max_passes <= 0: no limit (the worst case is one chunk per pass).  Returns the number of verify passes
+ * (>= 1) or a negative error. */
+int psxhip_adpcm_encode_chains_chunked(int device, const int16_t *d_samples, const psxhip_adpcm_chain_t *chains,
+                                       const int32_t *unit_base, int n_chains, int filter_count, int bits,
+                                       psxhip_adpcm_state_t *d_states, uint8_t *d_units, int chunk_units,
+                                       int warmup_units, int max_passes, void *stream);
+
 /* Pack n_blocks unit records into 16-byte SPU blocks (adpcm.c:367-372).  d_out 16-byte aligned. */
 int psxhip_spu_pack_device(int device, const uint8_t *d_units, int n_blocks, uint8_t *d_out, void *stream);
 

@@ -170,3 +170,78 @@ def psx_audio_xa_encode_finalize(settings, output):
 def psx_audio_xa_encode_simple(settings, samples, sample_count, lba, device=0):
     out = psx_audio_xa_encode(settings, EncoderState(), samples, sample_count, lba, device=device)
     return psx_audio_xa_encode_finalize(settings, out)
+
+
+# ---- device-resident paths (torch tensors) -----------------------------------------------------------
+CHAIN_DTYPE = np.dtype([("sample_offset", "<i8"), ("pitch", "<i4"), ("sample_limit", "<i4"), ("n_units", "<i4"),
+                        ("unit_stride", "<i4")])
+
+
+def make_chains(offsets, pitch, limits, n_units, unit_stride=1):
+    """Host-side psxhip_adpcm_chain_t array (include/psxav_hip.h)."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    ch = np.zeros(offsets.size, dtype=CHAIN_DTYPE)
+    ch["sample_offset"] = offsets
+    ch["pitch"] = pitch
+    ch["sample_limit"] = limits
+    ch["n_units"] = n_units
+    ch["unit_stride"] = unit_stride
+    return ch
+
+
+def encode_chains_device(d_samples, chains, unit_base, filter_count, bits, d_states=None, d_units=None, chunk_units=0,
+                         warmup_units=16, max_passes=0):
+    """Run the ADPCM search for `chains` (host CHAIN_DTYPE array) over int16 CUDA tensor `d_samples`.
+
+    chunk_units == 0: one serial pass per chain (psxhip_adpcm_encode_chains_device, asynchronous).
+    chunk_units  > 0: speculate-and-verify along time (psxhip_adpcm_encode_chains_chunked, synchronous).
+    Returns (d_units (total_units, 32) uint8, d_states (n_chains, 2) int32, verify_passes)."""
+    import torch
+    L = _bind()
+    L.psxhip_adpcm_encode_chains_chunked.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    dev = d_samples.device
+    chains = np.ascontiguousarray(chains, dtype=CHAIN_DTYPE)
+    unit_base = np.ascontiguousarray(unit_base, dtype=np.int32)
+    n = chains.size
+    total = int((unit_base + (chains["n_units"] - 1) * chains["unit_stride"]).max()) + 1 if n else 0
+    if d_states is None:
+        d_states = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    if d_units is None:
+        d_units = torch.zeros((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if chunk_units > 0:
+        rc = L.psxhip_adpcm_encode_chains_chunked(dev.index or 0, d_samples.data_ptr(), chains.ctypes.data, unit_base.ctypes.data,
+                                                  n, filter_count, bits, d_states.data_ptr(), d_units.data_ptr(), chunk_units,
+                                                  warmup_units, max_passes, st)
+        if rc < 0:
+            _lib.check(rc)
+        return d_units, d_states, rc
+    d_chains = torch.from_numpy(chains.view(np.uint8).reshape(n, CHAIN_DTYPE.itemsize).copy()).to(dev)
+    d_base = torch.from_numpy(unit_base).to(dev)
+    _lib.check(L.psxhip_adpcm_encode_chains_device(dev.index or 0, d_samples.data_ptr(), d_chains.data_ptr(), d_base.data_ptr(), n,
+                                                   filter_count, bits, d_states.data_ptr(), d_units.data_ptr(), st))
+    torch.cuda.current_stream(dev).synchronize()    # d_chains / d_base are temporaries
+    return d_units, d_states, 0
+
+
+def spu_pack_device(d_units, n_blocks):
+    import torch
+    L = _bind()
+    out = torch.empty((n_blocks, 16), dtype=torch.uint8, device=d_units.device)
+    st = torch.cuda.current_stream(d_units.device).cuda_stream
+    _lib.check(L.psxhip_spu_pack_device(d_units.device.index or 0, d_units.data_ptr(), n_blocks, out.data_ptr(), st))
+    return out
+
+
+def xa_assemble_device(d_units, n_sectors, settings, first_lba=0, d_eof=None):
+    import torch
+    L = _bind()
+    ssz = xa_get_buffer_size_per_sector(settings)
+    out = torch.empty((n_sectors, ssz), dtype=torch.uint8, device=d_units.device)
+    st = torch.cuda.current_stream(d_units.device).cuda_stream
+    _lib.check(L.psxhip_xa_assemble_device(d_units.device.index or 0, d_units.data_ptr(), n_sectors, settings.format,
+                                           int(settings.stereo), settings.frequency, settings.bits_per_sample,
+                                           settings.file_number, settings.channel_number, first_lba,
+                                           d_eof.data_ptr() if d_eof is not None else None, out.data_ptr(), st))
+    return out

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "psxhip_internal.h"
 
 namespace {
@@ -53,23 +55,125 @@ struct ChainJob {
     uint8_t* units;
 };
 
+// Per-lane constants of the candidate this lane owns inside its 16-lane row.
+struct Candidate {
+    int f, which, k1, k2;
+    bool live;
+    int range, qmin, qmax, qmask, half;
+};
+
+__device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, int range) {
+    Candidate c;
+    const int cand = lane & 15;
+    const int filter = cand / 3;
+    c.which = cand - filter * 3;
+    c.live = filter < filter_count;
+    c.f = c.live ? filter : 0;
+    // taps in 1/64 units (adpcm.c:36-37)
+    c.k1 = c.f == 0 ? 0 : c.f == 1 ? 60 : c.f == 2 ? 115 : c.f == 3 ? 98 : 122;
+    c.k2 = c.f == 0 ? 0 : c.f == 1 ? 0 : c.f == 2 ? -52 : c.f == 3 ? -55 : -60;
+    c.range = range;
+    c.qmin = -0x8000 >> range;
+    c.qmax = 0x7FFF >> range;
+    c.qmask = 0xFFFF >> range;
+    c.half = 1 << (range - 1);
+    return c;
+}
+
+// One sound unit for the 16-lane row this lane belongs to (adpcm.c:142-191 encode()): every lane tries its
+// own (filter, shift) candidate on the 28 samples x[], the row agrees on the winner, and (prev1, prev2)
+// advance to the winner's decoded state when `unit_live`.  Returns true on the winning lane, whose
+// `header` / `packed[7]` then hold the unit's record.
+__device__ __forceinline__ bool encode_unit(const Candidate& cd, const int (&x)[28], bool unit_live, int lane, int& prev1,
+                                            int& prev2, uint32_t& header, uint32_t (&packed)[7]) {
+    // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples
+    int lo = 0, hi = 0;
+    {
+        int p1 = prev1, p2 = prev2;
+#pragma unroll
+        for (int i = 0; i < 28; i++) {
+            const int r = x[i] - predict(cd.k1, cd.k2, p1, p2);
+            lo = r < lo ? r : lo;
+            hi = r > hi ? r : hi;
+            p2 = p1;
+            p1 = x[i];
+        }
+    }
+    int rs = 0;
+    while (rs < cd.range && (hi >> rs) > cd.qmax) rs++;
+    while (rs < cd.range && (lo >> rs) < cd.qmin) rs++;
+    const int m = cd.range - rs;
+    const int shift = m - 1 + cd.which;
+    const bool valid = unit_live && cd.live && shift >= 0 && shift <= cd.range;
+    const int sh = valid ? shift : 0;
+
+    // ---- attempt_to_encode for (filter, shift) (adpcm.c:81-140)
+    uint64_t sse = 0;
+    int p1 = prev1, p2 = prev2;
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = w * 4 + j;
+            const int pred = predict(cd.k1, cd.k2, p1, p2);
+            int q = (int)((uint32_t)(x[i] - pred) << sh);
+            q = (q + cd.half) >> cd.range;
+            q = q < cd.qmin ? cd.qmin : q;
+            q = q > cd.qmax ? cd.qmax : q;
+            q &= cd.qmask;
+            int dec = (int)(int16_t)(uint16_t)(q << cd.range);
+            dec = (dec >> sh) + pred;
+            dec = dec > 0x7FFF ? 0x7FFF : dec;
+            dec = dec < -0x8000 ? -0x8000 : dec;
+            const int err = dec - x[i];
+            sse += (uint64_t)((int64_t)err * (int64_t)err);
+            pk |= (uint32_t)q << (8 * j);
+            p2 = p1;
+            p1 = dec;
+        }
+        packed[w] = pk;
+    }
+
+    // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
+    const uint64_t key = valid ? ((sse << 8) | ((uint64_t)cd.f << 4) | (uint64_t)sh) : ~0ull;
+    const uint64_t best = row_min_u64(key);
+    const bool winner = valid && key == best;
+    const uint64_t wmask = __ballot(winner);
+    const int wlane = (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48);
+    header = (uint32_t)((sh & 0x0F) | (cd.f << 4));
+    const int np1 = __shfl(p1, wlane & 63, 64);
+    const int np2 = __shfl(p2, wlane & 63, 64);
+    if (unit_live) {
+        prev1 = np1;
+        prev2 = np2;
+    }
+    return winner;
+}
+
+// the 28 samples of chain-local unit u; samples at chain index >= sample_limit read as zero (adpcm.c:65,110)
+__device__ __forceinline__ void load_unit(const int16_t* src, const psxhip_adpcm_chain_t& ch, int u, bool live, int (&x)[28]) {
+    const int limit = ch.sample_limit - u * 28;
+#pragma unroll
+    for (int i = 0; i < 28; i++) {
+        int v = 0;
+        if (live && i < limit) v = src[(long long)(u * 28 + i) * ch.pitch];
+        x[i] = v;
+    }
+}
+
+__device__ __forceinline__ void store_record(uint8_t* units, long long index, uint32_t header, const uint32_t (&packed)[7]) {
+    uint32_t* rec = (uint32_t*)(units + index * kRecordBytes);
+    rec[0] = header;
+#pragma unroll
+    for (int w = 0; w < 7; w++) rec[1 + w] = packed[w];
+}
+
 __global__ __launch_bounds__(64) void adpcm_chains_kernel(const ChainJob job) {
     const int lane = (int)(threadIdx.x & 63);
-    const int cand = lane & 15;
     const int chain = (int)blockIdx.x * 4 + (lane >> 4);
     const bool chain_live = chain < job.n_chains;
-
-    // taps in 1/64 units (adpcm.c:36-37)
-    const int filter = cand / 3;
-    const int which = cand - filter * 3;
-    const bool cand_live = filter < job.filter_count;
-    const int f = cand_live ? filter : 0;
-    const int k1 = f == 0 ? 0 : f == 1 ? 60 : f == 2 ? 115 : f == 3 ? 98 : 122;
-    const int k2 = f == 0 ? 0 : f == 1 ? 0 : f == 2 ? -52 : f == 3 ? -55 : -60;
-
-    const int range = job.range;
-    const int qmin = -0x8000 >> range, qmax = 0x7FFF >> range, qmask = 0xFFFF >> range;
-    const int half = 1 << (range - 1);
+    const Candidate cd = make_candidate(lane, job.filter_count, job.range);
 
     psxhip_adpcm_chain_t ch;
     ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
@@ -90,88 +194,140 @@ __global__ __launch_bounds__(64) void adpcm_chains_kernel(const ChainJob job) {
 
     for (int u = 0; u < n_max; u++) {
         const bool unit_live = chain_live && u < ch.n_units;
-        const int limit = ch.sample_limit - u * 28;        // samples at i >= limit read as zero (adpcm.c:65,110)
-
         int x[28];
-#pragma unroll
-        for (int i = 0; i < 28; i++) {
-            int v = 0;
-            if (unit_live && i < limit) v = src[(long long)(u * 28 + i) * ch.pitch];
-            x[i] = v;
-        }
-
-        // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples
-        int lo = 0, hi = 0;
-        {
-            int p1 = prev1, p2 = prev2;
-#pragma unroll
-            for (int i = 0; i < 28; i++) {
-                const int r = x[i] - predict(k1, k2, p1, p2);
-                lo = r < lo ? r : lo;
-                hi = r > hi ? r : hi;
-                p2 = p1;
-                p1 = x[i];
-            }
-        }
-        int rs = 0;
-        while (rs < range && (hi >> rs) > qmax) rs++;
-        while (rs < range && (lo >> rs) < qmin) rs++;
-        const int m = range - rs;
-        const int shift = m - 1 + which;
-        const bool valid = unit_live && cand_live && shift >= 0 && shift <= range;
-        const int sh = valid ? shift : 0;
-
-        // ---- attempt_to_encode for (filter, shift) (adpcm.c:81-140)
-        uint64_t sse = 0;
-        uint32_t packed[7];
-        int p1 = prev1, p2 = prev2;
-#pragma unroll
-        for (int w = 0; w < 7; w++) {
-            uint32_t pk = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = w * 4 + j;
-                const int pred = predict(k1, k2, p1, p2);
-                int q = (int)((uint32_t)(x[i] - pred) << sh);
-                q = (q + half) >> range;
-                q = q < qmin ? qmin : q;
-                q = q > qmax ? qmax : q;
-                q &= qmask;
-                int dec = (int)(int16_t)(uint16_t)(q << range);
-                dec = (dec >> sh) + pred;
-                dec = dec > 0x7FFF ? 0x7FFF : dec;
-                dec = dec < -0x8000 ? -0x8000 : dec;
-                const int err = dec - x[i];
-                sse += (uint64_t)((int64_t)err * (int64_t)err);
-                pk |= (uint32_t)q << (8 * j);
-                p2 = p1;
-                p1 = dec;
-            }
-            packed[w] = pk;
-        }
-
-        // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
-        const uint64_t key = valid ? ((sse << 8) | ((uint64_t)f << 4) | (uint64_t)sh) : ~0ull;
-        const uint64_t best = row_min_u64(key);
-        const bool winner = valid && key == best;
-        const uint64_t wmask = __ballot(winner);
-        const int wlane = (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48);
-        if (winner) {
-            uint32_t* rec = (uint32_t*)(job.units + (rec0 + (long long)u * ch.unit_stride) * kRecordBytes);
-            rec[0] = (uint32_t)((sh & 0x0F) | (f << 4));
-#pragma unroll
-            for (int w = 0; w < 7; w++) rec[1 + w] = packed[w];
-        }
-        const int np1 = __shfl(p1, wlane & 63, 64);
-        const int np2 = __shfl(p2, wlane & 63, 64);
-        if (unit_live) {
-            prev1 = np1;
-            prev2 = np2;
-        }
+        load_unit(src, ch, u, unit_live, x);
+        uint32_t header, packed[7];
+        if (encode_unit(cd, x, unit_live, lane, prev1, prev2, header, packed))
+            store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, packed);
     }
-    if (chain_live && cand == 0) {
+    if (chain_live && (lane & 15) == 0) {
         job.states[chain].prev1 = prev1;
         job.states[chain].prev2 = prev2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Speculate-and-verify along time.  A chain is serial, but its whole carried state is the
+// pair (prev1, prev2), and encoders started from different states on the same samples usually fall into
+// the same state within a few units.  So a long chain is cut into chunks of `chunk_units`:
+//   speculate: every chunk is encoded in parallel, its start state guessed by running `warmup_units`
+//              units before the chunk from a zero state (chunk 0 starts from the chain's true state);
+//              the state after every unit is kept;
+//   verify:    every chunk compares the state it started from with the state its predecessor actually
+//              ended in; on a mismatch it re-encodes forward from the true state until its new state
+//              coincides with the stored one (from there on the stored records are already right).
+// verify is repeated until a pass changes nothing.  At that fixpoint every chunk was encoded from its
+// predecessor's final state by the deterministic unit encoder, i.e. the result equals the serial encode,
+// bit for bit, whatever the guesses were.  Worst case (states never coincide, e.g. pure tones) verify
+// advances one chunk per pass, which is the serial schedule.
+// ---------------------------------------------------------------------------------------------
+struct ChunkJob {
+    const int16_t* samples;
+    const psxhip_adpcm_chain_t* chains;
+    const int32_t* unit_base;        // record index of each chain's unit 0
+    const int64_t* state_base;       // index into unit_states of each chain's unit 0
+    const int32_t* chunk_chain;      // [n_chunks] chain of each chunk
+    const int32_t* chunk_first;      // [n_chunks] first unit (chain-local) of each chunk
+    int n_chunks, chunk_units, warmup_units;
+    int filter_count, range;
+    const psxhip_adpcm_state_t* chain_states;   // true start state of every chain
+    psxhip_adpcm_state_t* unit_states;          // state after every unit
+    psxhip_adpcm_state_t* start_used;           // [n_chunks] state each chunk was last encoded from
+    uint8_t* units;
+    int* changed;                    // verify: set to 1 when any chunk had to be re-encoded
+};
+
+template <bool VERIFY>
+__global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int chunk = (int)blockIdx.x * 4 + (lane >> 4);
+    const bool chunk_live = chunk < job.n_chunks;
+    const Candidate cd = make_candidate(lane, job.filter_count, job.range);
+
+    psxhip_adpcm_chain_t ch;
+    ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
+    int first = 0, count = 0, prev1 = 0, prev2 = 0, warm = 0;
+    long long rec0 = 0, st0 = 0;
+    bool active = false;
+    if (chunk_live) {
+        const int c = job.chunk_chain[chunk];
+        ch = job.chains[c];
+        first = job.chunk_first[chunk];
+        count = min(job.chunk_units, ch.n_units - first);
+        rec0 = job.unit_base[c];
+        st0 = job.state_base[c];
+        if (!VERIFY) {
+            active = true;
+            if (first == 0) {
+                prev1 = job.chain_states[c].prev1;
+                prev2 = job.chain_states[c].prev2;
+            } else {
+                warm = min(job.warmup_units, first);
+            }
+        } else if (first > 0) {
+            const psxhip_adpcm_state_t truth = job.unit_states[st0 + first - 1];
+            const psxhip_adpcm_state_t used = job.start_used[chunk];
+            if (truth.prev1 != used.prev1 || truth.prev2 != used.prev2) {
+                active = true;
+                prev1 = truth.prev1;
+                prev2 = truth.prev2;
+                if ((lane & 15) == 0) {
+                    job.start_used[chunk] = truth;
+                    *job.changed = 1;
+                }
+            }
+        }
+    }
+    const int16_t* src = job.samples + ch.sample_offset;
+
+    // ---- warm-up (speculate only): advance the state, keep nothing
+    int n_warm = active ? warm : 0;
+    int w_max = n_warm;
+    w_max = max(w_max, __shfl_xor(w_max, 16, 64));
+    w_max = max(w_max, __shfl_xor(w_max, 32, 64));
+    for (int t = 0; t < w_max; t++) {
+        const bool live = t < n_warm;
+        int x[28];
+        load_unit(src, ch, first - n_warm + t, live, x);
+        uint32_t header, packed[7];
+        (void)encode_unit(cd, x, live, lane, prev1, prev2, header, packed);
+    }
+    if (!VERIFY && chunk_live && (lane & 15) == 0) {
+        psxhip_adpcm_state_t s0;
+        s0.prev1 = prev1;
+        s0.prev2 = prev2;
+        job.start_used[chunk] = s0;
+    }
+
+    // ---- the chunk itself
+    int n_run = active ? count : 0;
+    int n_max = n_run;
+    n_max = max(n_max, __shfl_xor(n_max, 16, 64));
+    n_max = max(n_max, __shfl_xor(n_max, 32, 64));
+    bool running = active;
+    for (int t = 0; t < n_max; t++) {
+        const bool live = running && t < n_run;
+        if (!__any(live)) break;
+        const int u = first + t;
+        int x[28];
+        load_unit(src, ch, u, live, x);
+        uint32_t header, packed[7];
+        const bool winner = encode_unit(cd, x, live, lane, prev1, prev2, header, packed);
+        if (VERIFY && live) {
+            // coincided with the state stored for this unit: everything after it is already consistent
+            const psxhip_adpcm_state_t old = job.unit_states[st0 + u];
+            if (old.prev1 == prev1 && old.prev2 == prev2) {
+                // the record of THIS unit may still differ (different start, same end), so write it, then stop
+                running = false;
+            }
+        }
+        if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, packed);
+        if (live && (lane & 15) == 0) {
+            psxhip_adpcm_state_t s1;
+            s1.prev1 = prev1;
+            s1.prev2 = prev2;
+            job.unit_states[st0 + u] = s1;
+        }
     }
 }
 
@@ -357,6 +513,123 @@ extern "C" int psxhip_adpcm_encode_chains_device(int device, const int16_t* d_sa
         return PSXHIP_EDEVICE;
     }
     return PSXHIP_OK;
+}
+
+// final state of every chain = state after its last unit
+__global__ void adpcm_gather_final_states_kernel(const psxhip_adpcm_chain_t* chains, const int64_t* state_base, int n_chains,
+                                                 const psxhip_adpcm_state_t* unit_states, psxhip_adpcm_state_t* states) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_chains) return;
+    const int n = chains[c].n_units;
+    if (n > 0) states[c] = unit_states[state_base[c] + n - 1];
+}
+
+namespace {
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    template <typename T> T* as() { return (T*)p; }
+};
+}  // namespace
+
+extern "C" int psxhip_adpcm_encode_chains_chunked(int device, const int16_t* d_samples, const psxhip_adpcm_chain_t* chains,
+                                                  const int32_t* unit_base, int n_chains, int filter_count, int bits,
+                                                  psxhip_adpcm_state_t* d_states, uint8_t* d_units, int chunk_units,
+                                                  int warmup_units, int max_passes, void* stream) {
+    if (!d_samples || !chains || !unit_base || !d_states || !d_units || n_chains < 0 ||
+        (filter_count != 4 && filter_count != 5) || (bits != 4 && bits != 8) || chunk_units < 1 || warmup_units < 0 ||
+        ((uintptr_t)d_units & 3)) {
+        psxhip_set_error("adpcm_encode_chains_chunked: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    if (n_chains == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+
+    // chunk tables
+    std::vector<int64_t> state_base((size_t)n_chains);
+    std::vector<int32_t> chunk_chain, chunk_first;
+    int64_t total_units = 0;
+    for (int c = 0; c < n_chains; c++) {
+        state_base[(size_t)c] = total_units;
+        for (int f = 0; f < chains[c].n_units; f += chunk_units) {
+            chunk_chain.push_back(c);
+            chunk_first.push_back(f);
+        }
+        total_units += chains[c].n_units;
+    }
+    const int n_chunks = (int)chunk_chain.size();
+    if (n_chunks == 0) return 0;
+
+#define TRY(expr)                                                                                   \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            psxhip_set_error("%s failed: %s", #expr, hipGetErrorString(e__));                       \
+            return PSXHIP_EDEVICE;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_changed;
+    TRY(d_chains.alloc(sizeof(psxhip_adpcm_chain_t) * n_chains));
+    TRY(d_base.alloc(sizeof(int32_t) * n_chains));
+    TRY(d_sbase.alloc(sizeof(int64_t) * n_chains));
+    TRY(d_cchain.alloc(sizeof(int32_t) * n_chunks));
+    TRY(d_cfirst.alloc(sizeof(int32_t) * n_chunks));
+    TRY(d_ustates.alloc(sizeof(psxhip_adpcm_state_t) * (size_t)total_units));
+    TRY(d_used.alloc(sizeof(psxhip_adpcm_state_t) * n_chunks));
+    TRY(d_changed.alloc(sizeof(int)));
+    TRY(hipMemcpyAsync(d_chains.p, chains, sizeof(psxhip_adpcm_chain_t) * n_chains, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_base.p, unit_base, sizeof(int32_t) * n_chains, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_sbase.p, state_base.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_cchain.p, chunk_chain.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_cfirst.p, chunk_first.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
+
+    ChunkJob job;
+    job.samples = d_samples;
+    job.chains = d_chains.as<psxhip_adpcm_chain_t>();
+    job.unit_base = d_base.as<int32_t>();
+    job.state_base = d_sbase.as<int64_t>();
+    job.chunk_chain = d_cchain.as<int32_t>();
+    job.chunk_first = d_cfirst.as<int32_t>();
+    job.n_chunks = n_chunks;
+    job.chunk_units = chunk_units;
+    job.warmup_units = warmup_units;
+    job.filter_count = filter_count;
+    job.range = bits == 4 ? 12 : 8;
+    job.chain_states = d_states;
+    job.unit_states = d_ustates.as<psxhip_adpcm_state_t>();
+    job.start_used = d_used.as<psxhip_adpcm_state_t>();
+    job.units = d_units;
+    job.changed = d_changed.as<int>();
+
+    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(64);
+    hipLaunchKernelGGL(adpcm_chunks_kernel<false>, grid, block, 0, st, job);
+    TRY(hipGetLastError());
+    int passes = 0;
+    for (;;) {
+        TRY(hipMemsetAsync(d_changed.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(adpcm_chunks_kernel<true>, grid, block, 0, st, job);
+        TRY(hipGetLastError());
+        int changed = 0;
+        TRY(hipMemcpyAsync(&changed, d_changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        TRY(hipStreamSynchronize(st));
+        passes++;
+        if (!changed) break;
+        if (max_passes > 0 && passes >= max_passes) {
+            psxhip_set_error("adpcm_encode_chains_chunked: not converged after %d verify passes", passes);
+            return PSXHIP_EINVAL;
+        }
+    }
+    hipLaunchKernelGGL(adpcm_gather_final_states_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, st,
+                       d_chains.as<psxhip_adpcm_chain_t>(), d_sbase.as<int64_t>(), n_chains,
+                       d_ustates.as<psxhip_adpcm_state_t>(), d_states);
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(st));
+#undef TRY
+    return passes;
 }
 
 extern "C" int psxhip_spu_pack_device(int device, const uint8_t* d_units, int n_blocks, uint8_t* d_out, void* stream) {

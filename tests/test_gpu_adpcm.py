@@ -168,3 +168,101 @@ def test_against_reference_build_when_shipped():
         want, _ = O.ref_spu_encode(pcm)
         got = adpcm.spu_encode_streams(pcm.reshape(1, -1))[0]
         assert np.array_equal(got, want), trial
+
+
+# ---------------------------------------------------------------- speculate-and-verify along time
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5])
+def test_chunked_equals_serial_every_signal_class(kind):
+    """every chunk is encoded from a guessed state, verify passes repair the wrong guesses; the fixpoint must be the
+    serial encode bit for bit -- including class 4 (pure tone), where guesses essentially never coincide"""
+    import torch
+    from psxavenc_amd import adpcm
+    n_units = 700
+    n = n_units * 28
+    streams = 3
+    pcm = np.stack([O.synth_pcm(123, c, 77 * c, n, kind) for c in range(streams)])
+    d = torch.from_numpy(pcm).to("cuda:0")
+    chains = adpcm.make_chains(np.arange(streams) * n, 1, n, n_units)
+    base = np.arange(streams, dtype=np.int32) * n_units
+    d_units, d_states, passes = adpcm.encode_chains_device(d.reshape(-1), chains, base, 5, 4, chunk_units=32, warmup_units=8)
+    assert passes >= 1
+    got = adpcm.spu_pack_device(d_units, streams * n_units).cpu().numpy().reshape(streams, -1)
+    st = d_states.cpu().numpy()
+    for c in range(streams):
+        want, wst = O.spu_encode(pcm[c])
+        assert np.array_equal(got[c], want), (kind, c, passes)
+        assert st[c].tolist() == [wst.prev1, wst.prev2]
+
+
+def test_chunked_respects_initial_state_ragged_lengths_and_xa_layout():
+    """chains of different lengths, non-zero start states, stereo XA interleave (unit_stride 2, pitch 2), 8-bit"""
+    import torch
+    from psxavenc_amd import adpcm
+    # SPU: ragged lengths, carried-in state
+    lens = [1, 31, 32, 33, 257]
+    pcm = [O.synth_pcm(9, c, 0, 28 * u, 0) for c, u in enumerate(lens)]
+    offs = np.cumsum([0] + [p.size for p in pcm[:-1]])
+    d = torch.from_numpy(np.concatenate(pcm)).to("cuda:0")
+    chains = adpcm.make_chains(offs, 1, [p.size for p in pcm], lens)
+    base = np.cumsum([0] + lens[:-1]).astype(np.int32)
+    st0 = np.array([[100 * c, -50 * c] for c in range(len(lens))], np.int32)
+    d_states = torch.from_numpy(st0.copy()).to("cuda:0")
+    d_units, d_states, _ = adpcm.encode_chains_device(d, chains, base, 5, 4, d_states=d_states, chunk_units=16, warmup_units=4)
+    got = adpcm.spu_pack_device(d_units, sum(lens)).cpu().numpy().reshape(-1)
+    for c, u in enumerate(lens):
+        want, wst = O.spu_encode(pcm[c], state=O.Chan(int(st0[c, 0]), int(st0[c, 1])))
+        assert np.array_equal(got[base[c] * 16:(base[c] + u) * 16], want), c
+        assert d_states.cpu().numpy()[c].tolist() == [wst.prev1, wst.prev2]
+    # XA 8-bit stereo, 3 sectors
+    s = adpcm.XaSettings(1, True, 37800, 8, 2, 5)
+    n = 1008 * 3
+    inter = stereo_pad(0, n, 31, pad=0)
+    d = torch.from_numpy(inter).to("cuda:0")
+    units_per_chain = 3 * 18 * 4 // 2
+    chains = adpcm.make_chains([0, 1], 2, n, units_per_chain, unit_stride=2)
+    d_units, _, _ = adpcm.encode_chains_device(d, chains, np.array([0, 1], np.int32), 4, 8, chunk_units=10, warmup_units=6)
+    got = adpcm.xa_assemble_device(d_units, 3, s, first_lba=40).cpu().numpy().reshape(-1)
+    want, _ = O.xa_encode(O.XaSettings(1, 1, 37800, 8, 2, 5), np.concatenate([inter, np.zeros(8064, np.int16)]), n, lba=40)
+    assert np.array_equal(got, want)
+
+
+def test_chunked_long_chain_property():
+    """config 'xacd' chain shape at reduced length (200k units per chain x 4 chains, XA filter set)"""
+    import torch
+    from psxavenc_amd import adpcm, synth
+    n_units = 200000
+    n = n_units * 28
+    d = torch.empty((4, n), dtype=torch.int16, device="cuda:0")
+    for c in range(4):
+        synth.pcm_device(5, c, 0, n, 0, out=d[c])
+    chains = adpcm.make_chains(np.arange(4) * n, 1, n, n_units)
+    base = np.arange(4, dtype=np.int32) * n_units
+    d_units, d_states, passes = adpcm.encode_chains_device(d.reshape(-1), chains, base, 4, 4, chunk_units=64, warmup_units=16)
+    assert 1 <= passes < 200, passes      # tonal material converges slowly; the count only affects speed
+    got = adpcm.spu_pack_device(d_units, 4 * n_units).cpu().numpy().reshape(4, -1)
+    pcm = d.cpu().numpy()
+    for c in (0, 3):
+        # XA uses 4 filters: compare unit by unit through the oracle's unit encoder packed like SPU blocks
+        import ctypes as C
+        st = O.Chan(0, 0)
+        out = np.zeros(n_units * 16, np.uint8)
+        codes = (C.c_uint8 * 28)()
+        L = O.lib()
+        L.orc_adpcm_encode_unit.argtypes = [C.POINTER(O.Chan), O.i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        L.orc_adpcm_encode_unit.restype = C.c_uint8
+        x = np.ascontiguousarray(pcm[c])
+        # serial oracle over the chain, one unit per call (XA filter set: 4 filters)
+        hdrs = np.zeros(n_units, np.uint8)
+        blocks = np.zeros((n_units, 14), np.uint8)
+        for u in range(n_units):
+            h = L.orc_adpcm_encode_unit(C.byref(st), O.ptr(x[u * 28:], O.i16p), n - u * 28, 1, 4, 12, codes)
+            hdrs[u] = h
+            cc = np.frombuffer(codes, np.uint8)
+            blocks[u] = (cc[0::2] & 0x0F) | (cc[1::2] << 4)
+            if u >= 3000 and c == 3:
+                break
+        upto = 3001 if c == 3 else n_units
+        g = got[c].reshape(n_units, 16)
+        assert np.array_equal(g[:upto, 0], hdrs[:upto]) and np.array_equal(g[:upto, 2:], blocks[:upto])
+        if c == 0:
+            assert d_states.cpu().numpy()[0].tolist() == [st.prev1, st.prev2]
