@@ -122,6 +122,24 @@ int psxhip_adpcm_encode_chains_chunked(int device, const int16_t *d_samples, con
                                        psxhip_adpcm_state_t *d_states, uint8_t *d_units, int chunk_units,
                                        int warmup_units, int max_passes, void *stream);
 
+/* The same machinery as a persistent session, for sharding chains ALONG TIME across GPUs: a rank that owns units
+ * [a, b) of a chain does not know the state at `a` until its predecessor has finished.  lead_units[c] > 0 makes the
+ * session guess chain c's start state from up to `warmup_units` units located BEFORE the chain's sample_offset
+ * (they must be readable); psxhip_adpcm_session_run() (re)verifies everything against the start states passed in --
+ * call it again with corrected states after exchanging final states with the neighbour rank; it returns the
+ * number of verify passes and sets *any_change when any record was (re)written.  The fixpoint over all ranks
+ * (no rank changed) equals the serial encode.  See psxavenc_amd/parallel.py: encode_chains_time_sharded(). */
+typedef struct psxhip_adpcm_session psxhip_adpcm_session_t;
+int psxhip_adpcm_session_create(psxhip_adpcm_session_t **session, int device, const int16_t *d_samples,
+                                const psxhip_adpcm_chain_t *chains, const int32_t *unit_base,
+                                const int32_t *lead_units, int n_chains, int filter_count, int bits, uint8_t *d_units,
+                                int chunk_units, int warmup_units, void *stream);
+/* start_known (optional, [n_chains]): 0 = start_states[c] is not known yet -> keep the warm-up guess for chain c. */
+int psxhip_adpcm_session_run(psxhip_adpcm_session_t *session, const psxhip_adpcm_state_t *start_states,
+                             const uint8_t *start_known, int max_passes, psxhip_adpcm_state_t *final_states,
+                             int *any_change);
+void psxhip_adpcm_session_destroy(psxhip_adpcm_session_t *session);
+
 /* Pack n_blocks unit records into 16-byte SPU blocks (adpcm.c:367-372).  d_out 16-byte aligned. */
 int psxhip_spu_pack_device(int device, const uint8_t *d_units, int n_blocks, uint8_t *d_out, void *stream);
 

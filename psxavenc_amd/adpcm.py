@@ -245,3 +245,58 @@ def xa_assemble_device(d_units, n_sectors, settings, first_lba=0, d_eof=None):
                                            settings.file_number, settings.channel_number, first_lba,
                                            d_eof.data_ptr() if d_eof is not None else None, out.data_ptr(), st))
     return out
+
+
+class AdpcmSession:
+    """psxhip_adpcm_session_* (include/psxav_hip.h): a persistent speculate-and-verify encode of a set of chains, whose
+    start states can be corrected later (time-sharding across GPUs, psxavenc_amd/parallel.py)."""
+
+    def __init__(self, d_samples, chains, unit_base, filter_count, bits, d_units=None, lead_units=None, chunk_units=128,
+                 warmup_units=32):
+        import torch
+        L = _bind()
+        L.psxhip_adpcm_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.psxhip_adpcm_session_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.psxhip_adpcm_session_destroy.argtypes = [C.c_void_p]
+        L.psxhip_adpcm_session_destroy.restype = None
+        self._L = L
+        self.chains = np.ascontiguousarray(chains, dtype=CHAIN_DTYPE)
+        self.unit_base = np.ascontiguousarray(unit_base, dtype=np.int32)
+        self.n_chains = self.chains.size
+        dev = d_samples.device
+        total = int((self.unit_base + (self.chains["n_units"] - 1) * self.chains["unit_stride"]).max()) + 1 if self.n_chains else 0
+        self.d_units = d_units if d_units is not None else torch.zeros((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=dev)
+        self.d_samples = d_samples          # keep alive
+        lead = None if lead_units is None else np.ascontiguousarray(lead_units, dtype=np.int32)
+        self._h = C.c_void_p()
+        _lib.check(L.psxhip_adpcm_session_create(C.byref(self._h), dev.index or 0, d_samples.data_ptr(), self.chains.ctypes.data,
+                                                 self.unit_base.ctypes.data, lead.ctypes.data if lead is not None else None,
+                                                 self.n_chains, filter_count, bits, self.d_units.data_ptr(), chunk_units,
+                                                 warmup_units, torch.cuda.current_stream(dev).cuda_stream))
+        self.passes = 0
+
+    def run(self, start_states, known=None, max_passes=0):
+        """start_states (n_chains, 2) int32; known (n_chains,) bool/uint8 or None (= all known).
+        Returns (final_states (n_chains, 2) int32, changed: bool)."""
+        st = np.ascontiguousarray(start_states, dtype=np.int32).reshape(self.n_chains, 2)
+        kn = None if known is None else np.ascontiguousarray(known, dtype=np.uint8)
+        final = np.zeros((self.n_chains, 2), np.int32)
+        changed = C.c_int(0)
+        rc = self._L.psxhip_adpcm_session_run(self._h, st.ctypes.data, kn.ctypes.data if kn is not None else None, max_passes,
+                                              final.ctypes.data, C.byref(changed))
+        if rc < 0:
+            _lib.check(rc)
+        self.passes += rc
+        return final, bool(changed.value)
+
+    def close(self):
+        if self._h:
+            self._L.psxhip_adpcm_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -230,7 +230,10 @@ struct ChunkJob {
     const int32_t* chunk_first;      // [n_chunks] first unit (chain-local) of each chunk
     int n_chunks, chunk_units, warmup_units;
     int filter_count, range;
-    const psxhip_adpcm_state_t* chain_states;   // true start state of every chain
+    const psxhip_adpcm_state_t* chain_states;   // start state of every chain (the truth as far as it is known)
+    const int32_t* lead_units;                  // [n_chains] units available BEFORE the chain's first unit for guessing
+                                                //            its start state (0: start from chain_states as given)
+    const uint8_t* start_known;                 // [n_chains] 0: chain_states[c] is not known yet, keep the guess
     psxhip_adpcm_state_t* unit_states;          // state after every unit
     psxhip_adpcm_state_t* start_used;           // [n_chunks] state each chunk was last encoded from
     uint8_t* units;
@@ -256,17 +259,19 @@ __global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
         count = min(job.chunk_units, ch.n_units - first);
         rec0 = job.unit_base[c];
         st0 = job.state_base[c];
+        const int lead = job.lead_units[c];
         if (!VERIFY) {
             active = true;
-            if (first == 0) {
+            if (first == 0 && lead == 0) {
                 prev1 = job.chain_states[c].prev1;
                 prev2 = job.chain_states[c].prev2;
             } else {
-                warm = min(job.warmup_units, first);
+                warm = min(job.warmup_units, first + lead);   // may reach back before the chain (negative unit index)
             }
-        } else if (first > 0) {
-            const psxhip_adpcm_state_t truth = job.unit_states[st0 + first - 1];
+        } else {
             const psxhip_adpcm_state_t used = job.start_used[chunk];
+            const psxhip_adpcm_state_t truth = first > 0 ? job.unit_states[st0 + first - 1]
+                                                         : (job.start_known[c] ? job.chain_states[c] : used);
             if (truth.prev1 != used.prev1 || truth.prev2 != used.prev2) {
                 active = true;
                 prev1 = truth.prev1;
@@ -533,35 +538,13 @@ struct DevMem {
 };
 }  // namespace
 
-extern "C" int psxhip_adpcm_encode_chains_chunked(int device, const int16_t* d_samples, const psxhip_adpcm_chain_t* chains,
-                                                  const int32_t* unit_base, int n_chains, int filter_count, int bits,
-                                                  psxhip_adpcm_state_t* d_states, uint8_t* d_units, int chunk_units,
-                                                  int warmup_units, int max_passes, void* stream) {
-    if (!d_samples || !chains || !unit_base || !d_states || !d_units || n_chains < 0 ||
-        (filter_count != 4 && filter_count != 5) || (bits != 4 && bits != 8) || chunk_units < 1 || warmup_units < 0 ||
-        ((uintptr_t)d_units & 3)) {
-        psxhip_set_error("adpcm_encode_chains_chunked: bad argument");
-        return PSXHIP_EINVAL;
-    }
-    int rc = psxhip_ensure_device(device);
-    if (rc) return rc;
-    if (n_chains == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-
-    // chunk tables
-    std::vector<int64_t> state_base((size_t)n_chains);
-    std::vector<int32_t> chunk_chain, chunk_first;
-    int64_t total_units = 0;
-    for (int c = 0; c < n_chains; c++) {
-        state_base[(size_t)c] = total_units;
-        for (int f = 0; f < chains[c].n_units; f += chunk_units) {
-            chunk_chain.push_back(c);
-            chunk_first.push_back(f);
-        }
-        total_units += chains[c].n_units;
-    }
-    const int n_chunks = (int)chunk_chain.size();
-    if (n_chunks == 0) return 0;
+struct psxhip_adpcm_session {
+    int device, n_chains, n_chunks;
+    bool speculated;
+    hipStream_t stream;
+    ChunkJob job;
+    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_changed, d_cstates, d_lead, d_final, d_known;
+};
 
 #define TRY(expr)                                                                                   \
     do {                                                                                            \
@@ -572,65 +555,178 @@ extern "C" int psxhip_adpcm_encode_chains_chunked(int device, const int16_t* d_s
         }                                                                                           \
     } while (0)
 
-    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_changed;
-    TRY(d_chains.alloc(sizeof(psxhip_adpcm_chain_t) * n_chains));
-    TRY(d_base.alloc(sizeof(int32_t) * n_chains));
-    TRY(d_sbase.alloc(sizeof(int64_t) * n_chains));
-    TRY(d_cchain.alloc(sizeof(int32_t) * n_chunks));
-    TRY(d_cfirst.alloc(sizeof(int32_t) * n_chunks));
-    TRY(d_ustates.alloc(sizeof(psxhip_adpcm_state_t) * (size_t)total_units));
-    TRY(d_used.alloc(sizeof(psxhip_adpcm_state_t) * n_chunks));
-    TRY(d_changed.alloc(sizeof(int)));
-    TRY(hipMemcpyAsync(d_chains.p, chains, sizeof(psxhip_adpcm_chain_t) * n_chains, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_base.p, unit_base, sizeof(int32_t) * n_chains, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_sbase.p, state_base.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_cchain.p, chunk_chain.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_cfirst.p, chunk_first.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
+extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int device, const int16_t* d_samples,
+                                           const psxhip_adpcm_chain_t* chains, const int32_t* unit_base,
+                                           const int32_t* lead_units, int n_chains, int filter_count, int bits,
+                                           uint8_t* d_units, int chunk_units, int warmup_units, void* stream) {
+    if (!out) return PSXHIP_EINVAL;
+    *out = nullptr;
+    if (!d_samples || !chains || !unit_base || !d_units || n_chains < 0 || (filter_count != 4 && filter_count != 5) ||
+        (bits != 4 && bits != 8) || chunk_units < 1 || warmup_units < 0 || ((uintptr_t)d_units & 3)) {
+        psxhip_set_error("adpcm_session_create: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    psxhip_adpcm_session* s = new psxhip_adpcm_session();
+    s->device = device;
+    s->n_chains = n_chains;
+    s->speculated = false;
+    s->stream = (hipStream_t)stream;
 
-    ChunkJob job;
+    std::vector<int64_t> state_base((size_t)n_chains);
+    std::vector<int32_t> chunk_chain, chunk_first, lead((size_t)n_chains, 0);
+    int64_t total_units = 0;
+    for (int c = 0; c < n_chains; c++) {
+        state_base[(size_t)c] = total_units;
+        for (int f = 0; f < chains[c].n_units; f += chunk_units) {
+            chunk_chain.push_back(c);
+            chunk_first.push_back(f);
+        }
+        total_units += chains[c].n_units;
+        if (lead_units) lead[(size_t)c] = lead_units[c] < 0 ? 0 : lead_units[c];
+    }
+    s->n_chunks = (int)chunk_chain.size();
+    const int nc = n_chains ? n_chains : 1, nk = s->n_chunks ? s->n_chunks : 1;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = s->d_chains.alloc(sizeof(psxhip_adpcm_chain_t) * nc);
+    if (e == hipSuccess) e = s->d_base.alloc(sizeof(int32_t) * nc);
+    if (e == hipSuccess) e = s->d_sbase.alloc(sizeof(int64_t) * nc);
+    if (e == hipSuccess) e = s->d_lead.alloc(sizeof(int32_t) * nc);
+    if (e == hipSuccess) e = s->d_cstates.alloc(sizeof(psxhip_adpcm_state_t) * nc);
+    if (e == hipSuccess) e = s->d_final.alloc(sizeof(psxhip_adpcm_state_t) * nc);
+    if (e == hipSuccess) e = s->d_known.alloc(nc);
+    if (e == hipSuccess) e = s->d_cchain.alloc(sizeof(int32_t) * nk);
+    if (e == hipSuccess) e = s->d_cfirst.alloc(sizeof(int32_t) * nk);
+    if (e == hipSuccess) e = s->d_used.alloc(sizeof(psxhip_adpcm_state_t) * nk);
+    if (e == hipSuccess) e = s->d_ustates.alloc(sizeof(psxhip_adpcm_state_t) * (size_t)(total_units ? total_units : 1));
+    if (e == hipSuccess) e = s->d_changed.alloc(sizeof(int));
+    if (e != hipSuccess) {
+        psxhip_set_error("adpcm_session_create: hipMalloc failed: %s", hipGetErrorString(e));
+        delete s;
+        return PSXHIP_ENOMEM;
+    }
+    hipStream_t st = s->stream;
+    if (n_chains) {
+        TRY(hipMemcpyAsync(s->d_chains.p, chains, sizeof(psxhip_adpcm_chain_t) * n_chains, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(s->d_base.p, unit_base, sizeof(int32_t) * n_chains, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(s->d_sbase.p, state_base.data(), sizeof(int64_t) * n_chains, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(s->d_lead.p, lead.data(), sizeof(int32_t) * n_chains, hipMemcpyHostToDevice, st));
+    }
+    if (s->n_chunks) {
+        TRY(hipMemcpyAsync(s->d_cchain.p, chunk_chain.data(), sizeof(int32_t) * s->n_chunks, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(s->d_cfirst.p, chunk_first.data(), sizeof(int32_t) * s->n_chunks, hipMemcpyHostToDevice, st));
+    }
+    TRY(hipStreamSynchronize(st));    // the host vectors go out of scope
+
+    ChunkJob& job = s->job;
     job.samples = d_samples;
-    job.chains = d_chains.as<psxhip_adpcm_chain_t>();
-    job.unit_base = d_base.as<int32_t>();
-    job.state_base = d_sbase.as<int64_t>();
-    job.chunk_chain = d_cchain.as<int32_t>();
-    job.chunk_first = d_cfirst.as<int32_t>();
-    job.n_chunks = n_chunks;
+    job.chains = s->d_chains.as<psxhip_adpcm_chain_t>();
+    job.unit_base = s->d_base.as<int32_t>();
+    job.state_base = s->d_sbase.as<int64_t>();
+    job.chunk_chain = s->d_cchain.as<int32_t>();
+    job.chunk_first = s->d_cfirst.as<int32_t>();
+    job.n_chunks = s->n_chunks;
     job.chunk_units = chunk_units;
     job.warmup_units = warmup_units;
     job.filter_count = filter_count;
     job.range = bits == 4 ? 12 : 8;
-    job.chain_states = d_states;
-    job.unit_states = d_ustates.as<psxhip_adpcm_state_t>();
-    job.start_used = d_used.as<psxhip_adpcm_state_t>();
+    job.chain_states = s->d_cstates.as<psxhip_adpcm_state_t>();
+    job.lead_units = s->d_lead.as<int32_t>();
+    job.start_known = s->d_known.as<uint8_t>();
+    job.unit_states = s->d_ustates.as<psxhip_adpcm_state_t>();
+    job.start_used = s->d_used.as<psxhip_adpcm_state_t>();
     job.units = d_units;
-    job.changed = d_changed.as<int>();
+    job.changed = s->d_changed.as<int>();
+    *out = s;
+    return PSXHIP_OK;
+}
 
-    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(64);
-    hipLaunchKernelGGL(adpcm_chunks_kernel<false>, grid, block, 0, st, job);
-    TRY(hipGetLastError());
+extern "C" void psxhip_adpcm_session_destroy(psxhip_adpcm_session_t* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    delete s;
+}
+
+extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_adpcm_state_t* start_states,
+                                        const uint8_t* start_known, int max_passes, psxhip_adpcm_state_t* final_states,
+                                        int* any_change) {
+    if (!s || !start_states) {
+        psxhip_set_error("adpcm_session_run: NULL argument");
+        return PSXHIP_EINVAL;
+    }
+    if (any_change) *any_change = 0;
+    TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    if (s->n_chains == 0) return 0;
+    TRY(hipMemcpyAsync(s->d_cstates.p, start_states, sizeof(psxhip_adpcm_state_t) * s->n_chains, hipMemcpyHostToDevice, st));
+    if (start_known) TRY(hipMemcpyAsync(s->d_known.p, start_known, (size_t)s->n_chains, hipMemcpyHostToDevice, st));
+    else TRY(hipMemsetAsync(s->d_known.p, 1, (size_t)s->n_chains, st));
     int passes = 0;
-    for (;;) {
-        TRY(hipMemsetAsync(d_changed.p, 0, sizeof(int), st));
-        hipLaunchKernelGGL(adpcm_chunks_kernel<true>, grid, block, 0, st, job);
-        TRY(hipGetLastError());
-        int changed = 0;
-        TRY(hipMemcpyAsync(&changed, d_changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        TRY(hipStreamSynchronize(st));
-        passes++;
-        if (!changed) break;
-        if (max_passes > 0 && passes >= max_passes) {
-            psxhip_set_error("adpcm_encode_chains_chunked: not converged after %d verify passes", passes);
-            return PSXHIP_EINVAL;
+    if (s->n_chunks) {
+        const dim3 grid((unsigned)((s->n_chunks + 3) / 4)), block(64);
+        if (!s->speculated) {
+            hipLaunchKernelGGL(adpcm_chunks_kernel<false>, grid, block, 0, st, s->job);
+            TRY(hipGetLastError());
+            s->speculated = true;
+            if (any_change) *any_change = 1;
+        }
+        for (;;) {
+            TRY(hipMemsetAsync(s->d_changed.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(adpcm_chunks_kernel<true>, grid, block, 0, st, s->job);
+            TRY(hipGetLastError());
+            int changed = 0;
+            TRY(hipMemcpyAsync(&changed, s->d_changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            TRY(hipStreamSynchronize(st));
+            passes++;
+            if (!changed) break;
+            if (any_change) *any_change = 1;
+            if (max_passes > 0 && passes >= max_passes) {
+                psxhip_set_error("adpcm_session_run: not converged after %d verify passes", passes);
+                return PSXHIP_EINVAL;
+            }
         }
     }
-    hipLaunchKernelGGL(adpcm_gather_final_states_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, st,
-                       d_chains.as<psxhip_adpcm_chain_t>(), d_sbase.as<int64_t>(), n_chains,
-                       d_ustates.as<psxhip_adpcm_state_t>(), d_states);
+    // chains without units keep their start state
+    TRY(hipMemcpyAsync(s->d_final.p, s->d_cstates.p, sizeof(psxhip_adpcm_state_t) * s->n_chains, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(adpcm_gather_final_states_kernel, dim3((unsigned)((s->n_chains + 255) / 256)), dim3(256), 0, st,
+                       s->job.chains, s->job.state_base, s->n_chains, s->job.unit_states, s->d_final.as<psxhip_adpcm_state_t>());
     TRY(hipGetLastError());
+    if (final_states)
+        TRY(hipMemcpyAsync(final_states, s->d_final.p, sizeof(psxhip_adpcm_state_t) * s->n_chains, hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
-#undef TRY
     return passes;
 }
+
+extern "C" int psxhip_adpcm_encode_chains_chunked(int device, const int16_t* d_samples, const psxhip_adpcm_chain_t* chains,
+                                                  const int32_t* unit_base, int n_chains, int filter_count, int bits,
+                                                  psxhip_adpcm_state_t* d_states, uint8_t* d_units, int chunk_units,
+                                                  int warmup_units, int max_passes, void* stream) {
+    if (!d_states) {
+        psxhip_set_error("adpcm_encode_chains_chunked: bad argument");
+        return PSXHIP_EINVAL;
+    }
+    if (n_chains == 0) return 0;
+    psxhip_adpcm_session_t* s = nullptr;
+    int rc = psxhip_adpcm_session_create(&s, device, d_samples, chains, unit_base, nullptr, n_chains, filter_count, bits, d_units,
+                                         chunk_units, warmup_units, stream);
+    if (rc) return rc;
+    std::vector<psxhip_adpcm_state_t> st((size_t)n_chains);
+    hipError_t e = hipMemcpy(st.data(), d_states, sizeof(psxhip_adpcm_state_t) * n_chains, hipMemcpyDeviceToHost);
+    int passes = PSXHIP_EDEVICE;
+    if (e == hipSuccess) {
+        passes = psxhip_adpcm_session_run(s, st.data(), nullptr, max_passes, st.data(), nullptr);
+        if (passes >= 0) e = hipMemcpy(d_states, st.data(), sizeof(psxhip_adpcm_state_t) * n_chains, hipMemcpyHostToDevice);
+    }
+    psxhip_adpcm_session_destroy(s);
+    if (e != hipSuccess) {
+        psxhip_set_error("adpcm_encode_chains_chunked: state copy failed: %s", hipGetErrorString(e));
+        return PSXHIP_EDEVICE;
+    }
+    return passes;
+}
+#undef TRY
 
 extern "C" int psxhip_spu_pack_device(int device, const uint8_t* d_units, int n_blocks, uint8_t* d_out, void* stream) {
     if (!d_units || !d_out || n_blocks < 0 || ((uintptr_t)d_out & 15) || ((uintptr_t)d_units & 3)) {

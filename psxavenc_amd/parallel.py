@@ -65,3 +65,79 @@ def encode_frames_sharded(encoder, frame_source, n_frames_total, frame_max_sizes
         torch.cuda.synchronize(d_frames.device)
         dist.barrier()
     return first, d_out, d_res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ADPCM chains sharded ALONG TIME: the one place on this path with a real exchange step.
+# Rank r owns units [a_r, b_r) of every chain; the state at a_r is rank r-1's final state.  Every rank first
+# encodes from a guessed state (speculate-and-verify inside the rank), then ranks exchange their chains' final
+# states (an all-gather of 8 bytes per chain) and re-verify until a whole round changes nothing.  At that
+# fixpoint every rank started from its predecessor's final state, i.e. the concatenation equals the serial encode.
+# ---------------------------------------------------------------------------------------------------------
+def time_shard_protocol(session, rank, world, initial_states):
+    """Generator implementing one rank's side.  `session.run(start_states, known) -> (final_states, changed)`.
+    Yields (final_states, changed_flag); the driver sends back the list of all ranks' yields in rank order.
+    Returns (StopIteration.value) the chains' final states as seen by the LAST rank."""
+    import numpy as np
+    n = int(np.asarray(initial_states).shape[0])
+    start = np.asarray(initial_states, dtype=np.int32).reshape(n, 2).copy()
+    known = np.ones(n, np.uint8) if rank == 0 else np.zeros(n, np.uint8)
+    final, _ = session.run(start, known)
+    changed = True
+    for _ in range(world + 1):
+        gathered = yield (final.copy(), int(changed))
+        if not any(flag for (_, flag) in gathered):
+            return gathered[world - 1][0]
+        changed = False
+        if rank > 0:
+            truth = np.asarray(gathered[rank - 1][0], dtype=np.int32).reshape(n, 2)
+            if not known.all() or not np.array_equal(truth, start):
+                start = truth.copy()
+                known[:] = 1
+                new_final, rewrote = session.run(start, known)
+                changed = bool(rewrote) or not np.array_equal(new_final, final)
+                final = new_final
+    raise RuntimeError("time_shard_protocol: no fixpoint after world+1 rounds (cannot happen: truth advances one rank per round)")
+
+
+def run_time_sharded(session, rank, world, dist, initial_states, device=None):
+    """SPMD driver of time_shard_protocol over torch.distributed (RCCL on GPUs, gloo on CPU)."""
+    import numpy as np
+    import torch
+    gen = time_shard_protocol(session, rank, world, initial_states)
+    msg = next(gen)
+    while True:
+        final, flag = msg
+        payload = torch.tensor(np.concatenate([final.reshape(-1), [flag]]).astype(np.int64), device=device)
+        outs = [torch.zeros_like(payload) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(outs, payload)
+        else:
+            outs = [payload]
+        gathered = []
+        for o in outs:
+            v = o.cpu().numpy()
+            gathered.append((v[:-1].astype(np.int32).reshape(-1, 2), int(v[-1])))
+        try:
+            msg = gen.send(gathered)
+        except StopIteration as done:
+            return done.value
+
+
+def simulate_time_sharded(sessions, initial_states):
+    """Single-process lockstep driver (tests, single-GPU boxes): sessions[r] plays rank r."""
+    world = len(sessions)
+    gens = [time_shard_protocol(s, r, world, initial_states) for r, s in enumerate(sessions)]
+    msgs = [next(g) for g in gens]
+    while True:
+        results, done = [], 0
+        for g in gens:
+            try:
+                results.append(g.send(list(msgs)))
+            except StopIteration as fin:
+                results.append(fin.value)
+                done += 1
+        if done == world:
+            return results[-1]
+        assert done == 0, "ranks must finish in the same round"
+        msgs = results

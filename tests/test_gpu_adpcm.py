@@ -266,3 +266,32 @@ def test_chunked_long_chain_property():
         assert np.array_equal(g[:upto, 0], hdrs[:upto]) and np.array_equal(g[:upto, 2:], blocks[:upto])
         if c == 0:
             assert d_states.cpu().numpy()[0].tolist() == [st.prev1, st.prev2]
+
+
+def test_time_sharded_sessions_simulated_ranks():
+    """8(e) for ADPCM: chains sharded ALONG TIME over 4 (simulated) ranks on one GPU -- each rank's session guesses its
+    start state from the units before its range, ranks exchange final states until a round changes nothing"""
+    import torch
+    from psxavenc_amd import adpcm
+    from psxavenc_amd.parallel import shard_range, simulate_time_sharded
+    world, n_units, n_chains = 4, 1501, 3
+    n = n_units * 28
+    pcm = np.stack([O.synth_pcm(77, c, 0, n, k) for c, k in enumerate((0, 4, 5))])
+    d = torch.from_numpy(pcm).to("cuda:0").reshape(-1)
+    d_units = torch.zeros((n_chains * n_units, 32), dtype=torch.uint8, device="cuda:0")
+    sessions = []
+    for r in range(world):
+        first, count = shard_range(n_units, r, world)
+        chains = adpcm.make_chains(np.arange(n_chains) * n + first * 28, 1, n - first * 28, count)
+        base = (np.arange(n_chains) * n_units + first).astype(np.int32)
+        sessions.append(adpcm.AdpcmSession(d, chains, base, 5, 4, d_units=d_units, lead_units=np.full(n_chains, first, np.int32),
+                                           chunk_units=32, warmup_units=8))
+    init = np.array([[0, 0], [300, -300], [0, 0]], np.int32)
+    final = simulate_time_sharded(sessions, init)
+    got = adpcm.spu_pack_device(d_units, n_chains * n_units).cpu().numpy().reshape(n_chains, -1)
+    for c in range(n_chains):
+        want, wst = O.spu_encode(pcm[c], state=O.Chan(int(init[c, 0]), int(init[c, 1])))
+        assert np.array_equal(got[c], want), c
+        assert final[c].tolist() == [wst.prev1, wst.prev2]
+    for s in sessions:
+        s.close()
