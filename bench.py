@@ -41,7 +41,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
+    ap.add_argument("--workload", choices=["sbs", "xacd"], default="sbs",
+                    help="sbs = the headline MDEC metric (default); xacd = config 5, ADPCM-only XA sectors/s (secondary)")
+    ap.add_argument("--audio-seconds", type=float, default=120.0, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
+    ap.add_argument("--xa-channels", type=int, default=8)
     args = ap.parse_args()
+    if args.workload == "xacd":
+        return bench_xacd(args)
 
     import numpy as np
     import torch
@@ -164,6 +170,111 @@ def main():
         }
         print(json.dumps(line), flush=True)
     enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_xacd(args):
+    """Config 'xacd': 8 XA channels x stereo, 37800 Hz, 4-bit -> 2352-byte sectors.  16 serial chains; parallelism comes
+    from speculate-and-verify along time (psxhip_adpcm_session_*), and across GPUs from time-sharding with a final-state
+    all-gather (psxavenc_amd/parallel.py).  A step = encode the whole audio from scratch + assemble this rank's sectors."""
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from psxavenc_amd import adpcm, synth
+    from psxavenc_amd.parallel import run_time_sharded, shard_range
+
+    settings = adpcm.XaSettings(adpcm.PSX_AUDIO_XA_FORMAT_XACD, True, 37800, 4, 1, 0)
+    sps = adpcm.xa_get_samples_per_sector(settings)                      # 2016 sample frames per sector
+    n_sectors = max(world, int(args.audio_seconds * 37800 / sps))        # per channel
+    n_ch = args.xa_channels
+    sec0, sec_cnt = shard_range(n_sectors, rank, world)                  # this rank's sectors of every channel
+    units_per_sector_chain = 18 * 8 // 2                                 # per L/R chain
+    lead_sec = min(sec0, 1)                                              # one sector of history for the start-state guess
+    n_frames = (sec_cnt + lead_sec) * sps
+    pcm = torch.empty((n_ch, n_frames * 2), dtype=torch.int16, device=dev)
+    for c in range(n_ch):
+        for side in range(2):
+            synth.pcm_device(args.seed, 2 * c + side, (sec0 - lead_sec) * sps, n_frames, 0, device=local_rank,
+                             out=pcm[c][side:], pitch=2)
+    chains = adpcm.make_chains([(c * n_frames * 2 + lead_sec * sps * 2 + side) for c in range(n_ch) for side in range(2)], 2,
+                               sec_cnt * sps, sec_cnt * units_per_sector_chain, unit_stride=2)
+    base = np.array([c * sec_cnt * 144 + side for c in range(n_ch) for side in range(2)], np.int32)
+    lead = np.full(2 * n_ch, lead_sec * units_per_sector_chain, np.int32)
+    d_units = torch.zeros((n_ch * sec_cnt * 144, 32), dtype=torch.uint8, device=dev)
+    init = np.zeros((2 * n_ch, 2), np.int32)
+    torch.cuda.synchronize()
+
+    def step():
+        sess = adpcm.AdpcmSession(pcm.reshape(-1), chains, base, 4, 4, d_units=d_units, lead_units=lead, chunk_units=128, warmup_units=32)
+        run_time_sharded(sess, rank, world, dist, init, device=dev)
+        outs = [adpcm.xa_assemble_device(d_units[c * sec_cnt * 144:], sec_cnt, settings, first_lba=sec0) for c in range(n_ch)]
+        passes = sess.passes
+        sess.close()
+        return outs, passes
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs, passes = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    parity = None
+    cpu_baseline = None
+    if rank == 0:
+        import oracle_lib as O
+        k = min(sec_cnt, 40)
+        x = pcm[0][:(k * sps + 4032) * 2].cpu().numpy() if sec_cnt * sps >= k * sps + 4032 else np.concatenate(
+            [pcm[0].cpu().numpy(), np.zeros(8064, np.int16)])
+        os_ = O.XaSettings(1, 1, 37800, 4, 1, 0)
+        want, _ = O.xa_encode(os_, x, k * sps, lba=0)
+        got = outs[0][:k].cpu().numpy().reshape(-1)
+        parity = {"sectors_checked": int(k), "bit_exact": bool(np.array_equal(got, want))}
+        if world == 1 and not args.no_cpu_baseline:
+            c0 = time.perf_counter()
+            done = 0
+            while time.perf_counter() - c0 < args.cpu_seconds:
+                O.xa_encode(os_, x, k * sps, lba=0)
+                done += k
+            cpu_baseline = {"value": round(done / (time.perf_counter() - c0), 2), "unit": "sectors/s", "cores": 1, "kind": "port",
+                            "sample": "%d sectors of channel 0 (oracle/adpcm_oracle.c, gcc -O3)" % done}
+        total_sectors = n_sectors * n_ch * args.steps
+        value = total_sectors / elapsed
+        alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
+        print(json.dumps({
+            "metric": "xa_37800_4bit_stereo_sectors_per_sec", "value": round(value, 2), "unit": "sectors/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "xacd: %d XA channels x stereo x %.0f s @ 37800 Hz, 4-bit, %d sectors per channel, time-sharded x%d"
+                                   % (n_ch, n_sectors * sps / 37800.0, n_sectors, world),
+                       "verify_passes_last_step": passes, "realtime_factor": round(value * sps / 37800.0 / n_ch, 1)},
+            "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": None, "note": "whole step (sessions incl. host verify loop), not a single kernel"},
+            "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
