@@ -158,6 +158,7 @@ struct Lds {
     uint8_t* dc_plen;       // [16]
     uint8_t* dc_prefix;     // [16]
     int16_t* tiles;         // per-wave DCT staging
+    float2* qtab;           // [kScalesPerPass][64]  {1/(2 quant scale), 0.5 + 0.5/(2 quant scale)} for the current pass
     int* pass_bits;         // [kScalesPerPass] AC bits of the whole frame per scale
     int* scalars;           // [8]: 0 dc_bits, 1 chosen scale, 2 chosen index in pass, 3 nnz, 4 total bits
 };
@@ -177,6 +178,7 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    b += (size_t)kScalesPerPass * 64 * 8;   // qtab
     b += 64;                      // pass_bits + scalars
     return b;
 }
@@ -193,6 +195,7 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words) {
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
     L.tiles = (int16_t*)(base + b);       b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    L.qtab = (float2*)(base + b);         b += (size_t)kScalesPerPass * 64 * 8;
     L.pass_bits = (int*)(base + b);       b += kScalesPerPass * 4;
     L.scalars = (int*)(base + b);
     return L;
@@ -235,8 +238,8 @@ __device__ __forceinline__ int run_before(uint64_t nz_mask, const LaneConst& lc)
 // = 0 bits, so silent lanes need no predicate.  Only the LENGTH needs no level clamp at 510/512
 // (mdec.c:260-267): every level > MAX_LEVEL is an escape of the same length.
 __device__ __forceinline__ int lut_index(int q, int run) {
-    const int qc = q > BS_LUT_MAX_LEVEL + 1 ? BS_LUT_MAX_LEVEL + 1 : q;
-    return qc * BS_LUT_W + run;
+    const unsigned qc = (unsigned)q > (unsigned)(BS_LUT_MAX_LEVEL + 1) ? (unsigned)(BS_LUT_MAX_LEVEL + 1) : (unsigned)q;
+    return (int)__umul24(qc, (unsigned)BS_LUT_W) + run;     // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,16 +317,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         {
             // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
             const int g_row = lane >> 2, g_c4 = lane & 3;
-            const uint8_t* luma0 = frame + (size_t)g_row * W + g_c4 * 4;
-            const uint8_t* chroma0 = frame + (size_t)W * H + (size_t)(g_row & 7) * W + g_c4 * 4;
+            // all offsets are 32-bit (a frame is < 2^31 bytes); (fx, fy) advance incrementally, no divisions
+            const uint32_t luma_lane = (uint32_t)g_row * (uint32_t)W + (uint32_t)g_c4 * 4u;
+            const uint32_t chroma_lane = (uint32_t)W * (uint32_t)H + (uint32_t)(g_row & 7) * (uint32_t)W + (uint32_t)g_c4 * 4u;
+            int fy = wid / nx, fx = wid - fy * nx;           // once per frame per wavefront
             uint32_t yd = 0, cd = 0;
             if (wid < nmb) {
-                const int fy = wid / nx, fx = wid - fy * nx;
-                yd = *(const uint32_t*)(luma0 + (size_t)fy * 16 * W + fx * 16);
-                cd = *(const uint32_t*)(chroma0 + (size_t)fy * 8 * W + fx * 16);   // lanes >= 32 re-read rows 0..7 (unused)
+                yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
+                cd = *(const uint32_t*)(frame + (chroma_lane + (uint32_t)fy * 8u * (uint32_t)W + (uint32_t)fx * 16u));   // lanes >= 32 re-read rows 0..7 (unused)
             }
             for (int m = wid; m < nmb; m += kWavesPerGroup) {
-                const int fy = m / nx, fx = m - fy * nx;
                 const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
 
                 // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
@@ -340,11 +343,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 wave_sync();
                 // -- prefetch the next macroblock of this wavefront while this one is transformed
                 {
-                    const int mn = m + kWavesPerGroup;
-                    if (mn < nmb) {
-                        const int fyn = mn / nx, fxn = mn - fyn * nx;
-                        yd = *(const uint32_t*)(luma0 + (size_t)fyn * 16 * W + fxn * 16);
-                        cd = *(const uint32_t*)(chroma0 + (size_t)fyn * 8 * W + fxn * 16);
+                    fx += kWavesPerGroup;
+                    while (fx >= nx) { fx -= nx; fy++; }
+                    if (m + kWavesPerGroup < nmb) {
+                        yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
+                        cd = *(const uint32_t*)(frame + (chroma_lane + (uint32_t)fy * 8u * (uint32_t)W + (uint32_t)fx * 16u));
                     }
                 }
 
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 wave_sync();
 
                 // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, DC to LDS
-                int16_t* dst = slab + (size_t)mbe * 384 + lane;
+                int16_t* dst = slab + ((unsigned)mbe * 384u + (unsigned)lane);
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
                     const int c = tileZ[b * kZStride + lane];
@@ -481,19 +484,21 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         // =====================================================================================
         int scale0 = 1;   // first scale of the current pass
         for (;;) {
+            // quantiser constants of this pass, once per workgroup (IEEE division, not per macroblock)
+            if (tid < kScalesPerPass * 64) {
+                const int s_ = tid >> 6;
+                const float r = 1.0f / (float)(2 * (int)c_quant_zz[lane] * (scale0 + s_));
+                L.qtab[tid] = make_float2(r, 0.5f + 0.5f * r);
+            }
+            __syncthreads();
             {
-                float inv[kScalesPerPass], bias[kScalesPerPass];
-#pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) {
-                    inv[s] = 1.0f / (float)(2 * lc.quant * (scale0 + s));
-                    bias[s] = 0.5f + 0.5f * inv[s];
-                }
                 int wave_tot[kScalesPerPass];
 #pragma unroll
                 for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
 
                 for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                    const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                    const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
+                    const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
                     int acc01 = 0, acc23 = 0;      // two 16-bit counters per register (a macroblock's AC bits are < 2^14)
                     int cnext = src[0];
 #pragma unroll 1
@@ -502,10 +507,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                         if (b < 5) cnext = src[(b + 1) * 64];
                         const float two_abs = (float)(2 * (c < 0 ? -c : c));
                         static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
-                        const int q0 = quant_mag(two_abs, inv[0], bias[0]);
-                        const int q1 = quant_mag(two_abs, inv[1], bias[1]);
-                        const int q2 = quant_mag(two_abs, inv[2], bias[2]);
-                        const int q3 = quant_mag(two_abs, inv[3], bias[3]);
+                        const int q0 = quant_mag(two_abs, k0.x, k0.y);
+                        const int q1 = quant_mag(two_abs, k1.x, k1.y);
+                        const int q2 = quant_mag(two_abs, k2.x, k2.y);
+                        const int q3 = quant_mag(two_abs, k3.x, k3.y);
                         const int i0 = lut_index(q0, run_before(wave::ballot(q0 != 0), lc));
                         const int i1 = lut_index(q1, run_before(wave::ballot(q1 != 0), lc));
                         const int i2 = lut_index(q2, run_before(wave::ballot(q2 != 0), lc));
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             const uint32_t lane_tag = (uint32_t)lane << 11;
             int nnz = 0;
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                const int16_t* src = slab + (size_t)mbe * 384 + lane;
+                const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
                 // ---- 1. compaction
                 int count = 0;                             // wave-uniform
                 int cnext = src[0];
