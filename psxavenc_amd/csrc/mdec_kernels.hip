@@ -389,17 +389,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 }
                 wave_sync();
 
-                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, DC to LDS
+                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab
                 int16_t* dst = slab + ((unsigned)mbe * 384u + (unsigned)lane);
 #pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    const int c = tileZ[b * kZStride + lane];
-                    dst[b * 64] = (int16_t)c;
-                    if (lane == 0) {
-                        const int dc = quant_dc(c);
-                        // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
-                        L.dcw[mbe * 6 + b] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
-                    }
+                for (int b = 0; b < 6; b++) dst[b * 64] = tileZ[b * kZStride + lane];
+                // -- the six DC terms, one lane each
+                if (lane < 6) {
+                    const int dc = quant_dc((int)tileZ[lane * kZStride]);
+                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
+                    L.dcw[mbe * 6 + lane] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
                 }
                 wave_sync();   // tileZ is the next iteration's pixel tile
             }
@@ -613,28 +611,22 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             const float inv1 = 1.0f / (float)(2 * lc.quant * scale), bias1 = 0.5f + 0.5f * inv1;
             uint32_t* stream = L.out + 2;                  // bitstream starts at byte 8 (mdec.c:686)
             uint32_t* clist = (uint32_t*)tileT;            // the DCT tiles are idle now: 384 entries fit (kWaveTileBytes >= 1536)
-            const uint32_t lane_tag = (uint32_t)lane << 11;
+            const uint32_t lane_tag = (uint32_t)lane << 13;
             int nnz = 0;
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
                 const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
-                // ---- 1. compaction
+                // ---- 1. compaction.  Entry: [11:0] unclamped |level|, [12] sign, [18:13] scan position.
+                //      Lane 0 (scan position 0) is always kept: it marks the block's DC slot.
                 int count = 0;                             // wave-uniform
                 int cnext = src[0];
 #pragma unroll 1
                 for (int b = 0; b < 6; b++) {
-                    const int c = cnext;
+                    const int c = lane == 0 ? 0 : cnext;       // the DC term is not an AC level (its raw quotient would not fit 12 bits)
                     if (b < 5) cnext = src[(b + 1) * 64];
-                    const bool neg = c < 0;
-                    int q = quant_mag((float)(2 * (neg ? -c : c)), inv1, bias1);
-                    const int lim = neg ? 512 : 510;       // level clamp, mdec.c:260-267
-                    q = q > lim ? lim : q;
-                    const bool keep = lane == 0 || q != 0;
-                    const uint64_t m = wave::ballot(keep);
-                    if (keep) {
-                        // [9:0] |level| (lane 0: block index), [10] sign, [16:11] scan position
-                        const uint32_t payload = lane == 0 ? (uint32_t)b : ((uint32_t)q | (neg ? 0x400u : 0u));
-                        clist[count + wave::popc_below(m)] = payload | lane_tag;
-                    }
+                    const int q = quant_mag((float)(2 * (c < 0 ? -c : c)), inv1, bias1);     // <= 2048
+                    const uint64_t m = wave::ballot(q != 0) | 1ull;
+                    if (q != 0 || lane == 0)
+                        clist[count + wave::popc_below(m)] = (uint32_t)q | (((uint32_t)c >> 19) & 0x1000u) | lane_tag;
                     const int n = (int)__builtin_popcountll(m);
                     count += n;
                     nnz += n - 1;
@@ -643,27 +635,33 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
 
                 // ---- 2. codes
                 uint32_t pos = L.mb_off[mbe] - (mbe > 0 ? 2u : 0u);   // the previous macroblock's last end-of-block code starts here
-                int kcarry = 0;
+                int kcarry = 0, bcarry = 0;
                 for (int base = 0; base < count; base += 64) {
                     const int i = base + lane;
                     const bool live = i < count;
-                    const uint32_t e = live ? clist[i] : 0u;
-                    const int k = (int)(e >> 11);
-                    const int q = (int)(e & 0x3FFu);
-                    const bool neg = (e & 0x400u) != 0;
+                    const uint32_t e = live ? clist[i] : 0xFFFFFFFFu;      // dead lanes: scan position 63, never a DC slot
+                    const int k = (int)((e >> 13) & 63u);
+                    const bool neg = (e & 0x1000u) != 0;
                     const bool is_dc = k == 0;
-                    int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
-                    const int run = is_dc ? 0 : k - kprev - 1;
-                    const uint32_t entry = L.ac_code[lut_index(is_dc ? 0 : q, run)];
+                    int q = (int)(e & 0xFFFu);
+                    const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
+                    q = q > lim ? lim : q;
+                    const int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                    const bool is_ac = live && !is_dc;
+                    const int run = is_ac ? k - kprev - 1 : 0;
+                    const uint32_t entry = L.ac_code[lut_index(is_ac ? q : 0, run)];
                     const int sl = neg ? -q : q;
                     const uint32_t esc = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
                     int len = (int)(entry >> 24);
                     uint32_t code = len == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
-                    if (is_dc && live) {
-                        const uint32_t dcw = L.dcw[mbe * 6 + q];      // q holds the block index for DC entries
+                    // DC slots: block index = number of DC slots before this one in the macroblock's list
+                    const uint64_t dcmask = wave::ballot(is_dc);
+                    if (is_dc) {
+                        const int blk = bcarry + wave::popc_below(dcmask);
+                        const uint32_t dcw = L.dcw[mbe * 6 + blk];
                         len = (int)(dcw >> 24);
                         code = dcw & 0xFFFFFFu;
-                        if (q > 0 || mbe > 0) {                        // carry the previous block's end-of-block code
+                        if (blk > 0 || mbe > 0) {                   // carry the previous block's end-of-block code
                             code |= 2u << len;
                             len += 2;
                         }
@@ -672,6 +670,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                     if (len) put_bits(stream, pos + (uint32_t)(incl - len), len, code);
                     pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                     kcarry = __builtin_amdgcn_readlane(k, 63);
+                    bcarry += (int)__builtin_popcountll(dcmask);
                 }
                 wave_sync();   // the list is rewritten by the next macroblock
             }
