@@ -242,6 +242,49 @@ __device__ __forceinline__ int lut_index(int q, int run) {
     return (int)__umul24(qc, (unsigned)BS_LUT_W) + run;     // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
 }
 
+// AC bits of one block at the four scales of a pass; two 16-bit counters per accumulator register.
+__device__ __forceinline__ void count_block4(int c, int lane, const float2& k0, const float2& k1, const float2& k2,
+                                             const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
+                                             int& acc23) {
+    static_assert(kScalesPerPass == 4, "count_block4 evaluates 4 scales");
+    c = lane == 0 ? 0 : c;
+    const float two_abs = (float)(2 * (c < 0 ? -c : c));
+    const int q0 = quant_mag(two_abs, k0.x, k0.y);
+    const int q1 = quant_mag(two_abs, k1.x, k1.y);
+    const int q2 = quant_mag(two_abs, k2.x, k2.y);
+    const int q3 = quant_mag(two_abs, k3.x, k3.y);
+    const int i0 = lut_index(q0, run_before(wave::ballot(q0 != 0), lc));
+    const int i1 = lut_index(q1, run_before(wave::ballot(q1 != 0), lc));
+    const int i2 = lut_index(q2, run_before(wave::ballot(q2 != 0), lc));
+    const int i3 = lut_index(q3, run_before(wave::ballot(q3 != 0), lc));
+    acc01 += (int)ac_len[i0] | ((int)ac_len[i1] << 16);
+    acc23 += (int)ac_len[i2] | ((int)ac_len[i3] << 16);
+}
+
+// per-macroblock sums of the packed counters -> LDS, and into the wavefront's running totals
+__device__ __forceinline__ void count_finish4(int acc01, int acc23, int lane, uint16_t* mb_bits_slot, int (&wave_tot)[kScalesPerPass]) {
+    const int t01 = wave::reduce_add(acc01);
+    const int t23 = wave::reduce_add(acc23);
+    wave_tot[0] += t01 & 0xFFFF;
+    wave_tot[1] += (unsigned)t01 >> 16;
+    wave_tot[2] += t23 & 0xFFFF;
+    wave_tot[3] += (unsigned)t23 >> 16;
+    if (lane == 0) {
+        uint2 v;
+        v.x = (uint32_t)t01;
+        v.y = (uint32_t)t23;
+        *(uint2*)mb_bits_slot = v;
+    }
+}
+
+__device__ __forceinline__ void fill_qtab(float2* qtab, int tid, int lane, int scale0) {
+    // quantiser constants of a pass, once per workgroup (IEEE division, not per macroblock)
+    if (tid < kScalesPerPass * 64) {
+        const float r = 1.0f / (float)(2 * (int)c_quant_zz[lane] * (scale0 + (tid >> 6)));
+        qtab[tid] = make_float2(r, 0.5f + 0.5f * r);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register budget: the kernel is compiled for 8 wavefronts per SIMD (<= 64 VGPRs), i.e. two frames in
 // flight per CU.  The hot path is latency-bound (LDS look-ups, DPP scans, ballots), so it is written
@@ -308,11 +351,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
         if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
         if (tid < 8) L.scalars[tid] = 0;
+        fill_qtab(L.qtab, tid, lane, 1);
         __syncthreads();
         clk.mark(0);
 
         // =====================================================================================
-        // (A) DCT of every macroblock -> coefficient slab (zig-zag order) + quantised DC
+        // (A) DCT of every macroblock -> coefficient slab (zig-zag order) + quantised DC, fused with the first
+        //     count pass (scales 1..kScalesPerPass) while the coefficients are still in LDS
         // =====================================================================================
         {
             // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
@@ -321,6 +366,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             const uint32_t luma_lane = (uint32_t)g_row * (uint32_t)W + (uint32_t)g_c4 * 4u;
             const uint32_t chroma_lane = (uint32_t)W * (uint32_t)H + (uint32_t)(g_row & 7) * (uint32_t)W + (uint32_t)g_c4 * 4u;
             int fy = wid / nx, fx = wid - fy * nx;           // once per frame per wavefront
+            int wave_tot[kScalesPerPass];
+#pragma unroll
+            for (int s_ = 0; s_ < kScalesPerPass; s_++) wave_tot[s_] = 0;
             uint32_t yd = 0, cd = 0;
             if (wid < nmb) {
                 yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
@@ -389,10 +437,19 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 }
                 wave_sync();
 
-                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab
+                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, and counted at scales 1..4
                 int16_t* dst = slab + ((unsigned)mbe * 384u + (unsigned)lane);
-#pragma unroll
-                for (int b = 0; b < 6; b++) dst[b * 64] = tileZ[b * kZStride + lane];
+                {
+                    const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
+                    int acc01 = 0, acc23 = 0;
+#pragma unroll 1
+                    for (int b = 0; b < 6; b++) {
+                        const int c = tileZ[b * kZStride + lane];
+                        dst[b * 64] = (int16_t)c;
+                        count_block4(c, lane, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
+                    }
+                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
+                }
                 // -- the six DC terms, one lane each
                 if (lane < 6) {
                     const int dc = quant_dc((int)tileZ[lane * kZStride]);
@@ -400,6 +457,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                     L.dcw[mbe * 6 + lane] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
                 }
                 wave_sync();   // tileZ is the next iteration's pixel tile
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int s_ = 0; s_ < kScalesPerPass; s_++) atomicAdd(&L.pass_bits[s_], wave_tot[s_]);
             }
         }
         __syncthreads();
@@ -480,61 +541,33 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         // (B) Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723),
         //     kScalesPerPass scales per pass over the slab
         // =====================================================================================
-        int scale0 = 1;   // first scale of the current pass
+        int scale0 = 1;   // first scale of the current pass; scales 1..kScalesPerPass were counted in (A)
         for (;;) {
-            // quantiser constants of this pass, once per workgroup (IEEE division, not per macroblock)
-            if (tid < kScalesPerPass * 64) {
-                const int s_ = tid >> 6;
-                const float r = 1.0f / (float)(2 * (int)c_quant_zz[lane] * (scale0 + s_));
-                L.qtab[tid] = make_float2(r, 0.5f + 0.5f * r);
-            }
-            __syncthreads();
-            {
+            if (scale0 > 1) {
+                fill_qtab(L.qtab, tid, lane, scale0);
+                __syncthreads();
                 int wave_tot[kScalesPerPass];
 #pragma unroll
-                for (int s = 0; s < kScalesPerPass; s++) wave_tot[s] = 0;
-
+                for (int s_ = 0; s_ < kScalesPerPass; s_++) wave_tot[s_] = 0;
                 for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
                     const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
                     const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
-                    int acc01 = 0, acc23 = 0;      // two 16-bit counters per register (a macroblock's AC bits are < 2^14)
+                    int acc01 = 0, acc23 = 0;
                     int cnext = src[0];
 #pragma unroll 1
                     for (int b = 0; b < 6; b++) {
-                        int c = lane == 0 ? 0 : cnext;
+                        const int c = cnext;
                         if (b < 5) cnext = src[(b + 1) * 64];
-                        const float two_abs = (float)(2 * (c < 0 ? -c : c));
-                        static_assert(kScalesPerPass == 4, "packing below assumes 4 scales per pass");
-                        const int q0 = quant_mag(two_abs, k0.x, k0.y);
-                        const int q1 = quant_mag(two_abs, k1.x, k1.y);
-                        const int q2 = quant_mag(two_abs, k2.x, k2.y);
-                        const int q3 = quant_mag(two_abs, k3.x, k3.y);
-                        const int i0 = lut_index(q0, run_before(wave::ballot(q0 != 0), lc));
-                        const int i1 = lut_index(q1, run_before(wave::ballot(q1 != 0), lc));
-                        const int i2 = lut_index(q2, run_before(wave::ballot(q2 != 0), lc));
-                        const int i3 = lut_index(q3, run_before(wave::ballot(q3 != 0), lc));
-                        acc01 += (int)L.ac_len[i0] | ((int)L.ac_len[i1] << 16);
-                        acc23 += (int)L.ac_len[i2] | ((int)L.ac_len[i3] << 16);
+                        count_block4(c, lane, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
                     }
-                    const int t01 = wave::reduce_add(acc01);
-                    const int t23 = wave::reduce_add(acc23);
-                    wave_tot[0] += t01 & 0xFFFF;
-                    wave_tot[1] += (unsigned)t01 >> 16;
-                    wave_tot[2] += t23 & 0xFFFF;
-                    wave_tot[3] += (unsigned)t23 >> 16;
-                    if (lane == 0) {
-                        uint2 v;
-                        v.x = (uint32_t)t01;
-                        v.y = (uint32_t)t23;
-                        *(uint2*)&L.mb_bits[mbe * kScalesPerPass] = v;
-                    }
+                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
                 }
                 if (lane == 0) {
 #pragma unroll
-                    for (int s = 0; s < kScalesPerPass; s++) atomicAdd(&L.pass_bits[s], wave_tot[s]);
+                    for (int s_ = 0; s_ < kScalesPerPass; s_++) atomicAdd(&L.pass_bits[s_], wave_tot[s_]);
                 }
+                __syncthreads();
             }
-            __syncthreads();
 
             if (tid == 0) {
                 const int fixed = L.scalars[0] + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
