@@ -115,7 +115,8 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
         free(c);
         return PSXHIP_EINVAL;
     }
-    HIP_TRY(psxhip_mdec_set_max_lds(codec, c->lds_bytes), PSXHIP_EDEVICE);
+    // opt the kernel into the whole LDS once (contexts with different geometries share the kernel attribute)
+    HIP_TRY(psxhip_mdec_set_max_lds(codec, (size_t)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
     int per_cu = (int)((size_t)prop.maxSharedMemoryPerMultiProcessor / c->lds_bytes);
     const int by_threads = prop.maxThreadsPerMultiProcessor / psxhip_mdec_threads_per_group();
     if (per_cu > by_threads) per_cu = by_threads;

@@ -207,3 +207,21 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(_lib.PsxHipError):
         enc.encode_frames_host(np.zeros((1, 320 * 240 * 3 // 2), np.uint8), 9000)     # above the context's maximum
     enc.close()
+
+
+def test_two_contexts_with_different_lds_needs_coexist():
+    """the kernel's dynamic-LDS attribute is per kernel, not per context: a small context created after a large one must
+    not break the large one (640x512 is the largest size the reference's CLI accepts, args.c:410-421)"""
+    big = encoder(1, 640, 512, 40000)
+    small = encoder(1, 48, 32, 4096)
+    fr_b = O.synth_frames(640, 512, 2, seed=4, amp=8)
+    fr_s = O.synth_frames(48, 32, 2, seed=4, amp=8)
+    want_b, res_b, rc_b = O.mdec_encode(1, 640, 512, fr_b, 40000)
+    want_s, res_s, rc_s = O.mdec_encode(1, 48, 32, fr_s, 4096)
+    assert rc_b == 0 and rc_s == 0
+    out_s, r_s = small.encode_frames_host(fr_s, 4096)
+    out_b, r_b = big.encode_frames_host(fr_b, 40000)
+    assert_same(out_b, r_b, want_b, res_b, "640x512")
+    assert_same(out_s, r_s, want_s, res_s, "48x32")
+    big.close()
+    small.close()
