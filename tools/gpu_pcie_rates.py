@@ -1,0 +1,21 @@
+"""PCIe-inclusive rates of the host-buffer entry points."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from psxavenc_amd.mdec import MdecEncoder
+w, h, budget = 320, 240, 8192
+fr = O.synth_frames(w, h, 1000, seed=1, amp=4)
+enc = MdecEncoder(0, w, h, max_frame_size=budget)
+enc.frame_max_size = budget
+for k in range(20): enc.encode_frame_bs(fr[k])
+t = time.perf_counter()
+for k in range(500): enc.encode_frame_bs(fr[k])
+dt = time.perf_counter() - t
+print("encode_frame_bs (one frame per call, pageable host buffers): %.0f frames/s (%.1f us per call)" % (500 / dt, dt / 500 * 1e6))
+enc.encode_frames_host(fr, budget)
+t = time.perf_counter()
+for _ in range(5): enc.encode_frames_host(fr, budget)
+dt = (time.perf_counter() - t) / 5
+print("encode_frames_host (1000 frames per call, pageable host buffers, H2D+kernel+D2H): %.0f frames/s (%.2f ms per call)" % (1000 / dt, dt * 1e3))
