@@ -303,6 +303,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
     const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
     const int nblk = nmb * 6;
 
+    PhaseClock clk;
+    clk.start(job.timing);
+
     // ---- once per workgroup: LUTs into LDS, per-lane constants
     for (int i = tid; i < BS_LUT_SIZE; i += kThreads) {
         L.ac_len[i] = c_ac_len[i];
@@ -339,8 +342,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
 
     int16_t* slab = job.coef_slab + (size_t)blockIdx.x * nmb * 384;
 
-    PhaseClock clk;
-    clk.start(job.timing);
+    clk.mark(7);   // per-workgroup prologue
 
     for (int f = (int)blockIdx.x; f < job.n_frames; f += (int)gridDim.x) {
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;

@@ -19,6 +19,7 @@ for amp in (4, 8):
     for _ in range(10): enc.encode_frames_device(d, budget)
     e1.record(); torch.cuda.synchronize()
     L.psxhip_mdec_read_timing(enc._h, t, 1)
-    v = np.array(list(t), dtype=np.float64); tot = v.sum()
-    print("amp", amp, "ms/launch %.4f" % (e0.elapsed_time(e1) / 10), "phase %:", np.round(100 * v / tot, 1).tolist(), "cycles/frame %.0f" % (tot / (10 * n)))
+    v = np.array(list(t), dtype=np.float64); tot = v[:7].sum()
+    wgs = min(n, 512)
+    print("amp", amp, "prologue cycles/WG %.0f" % (v[7] / (10 * wgs)), "ms/launch %.4f" % (e0.elapsed_time(e1) / 10), "phase %:", np.round(100 * v / tot, 1).tolist(), "cycles/frame %.0f" % (tot / (10 * n)))
     enc.close()
