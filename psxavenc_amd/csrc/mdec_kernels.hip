@@ -243,11 +243,11 @@ __device__ __forceinline__ int lut_index(int q, int run) {
 }
 
 // AC bits of one block at the four scales of a pass; two 16-bit counters per accumulator register.
-__device__ __forceinline__ void count_block4(int c, int lane, const float2& k0, const float2& k1, const float2& k2,
+// (the DC slot of every block is stored as 0, so lane 0 never produces a level)
+__device__ __forceinline__ void count_block4(int c, const float2& k0, const float2& k1, const float2& k2,
                                              const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
                                              int& acc23) {
     static_assert(kScalesPerPass == 4, "count_block4 evaluates 4 scales");
-    c = lane == 0 ? 0 : c;
     const float two_abs = (float)(2 * (c < 0 ? -c : c));
     const int q0 = quant_mag(two_abs, k0.x, k0.y);
     const int q1 = quant_mag(two_abs, k1.x, k1.y);
@@ -439,6 +439,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 }
                 wave_sync();
 
+                // -- the six DC terms, one lane each; the DC slot is then zeroed so that the AC path (here, in later
+                //    count passes and in emit) sees "no coefficient" at scan position 0 without a per-lane select
+                if (lane < 6) {
+                    const int dc = quant_dc((int)tileZ[lane * kZStride]);
+                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
+                    L.dcw[mbe * 6 + lane] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                    tileZ[lane * kZStride] = 0;
+                }
+                wave_sync();
                 // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, and counted at scales 1..4
                 int16_t* dst = slab + ((unsigned)mbe * 384u + (unsigned)lane);
                 {
@@ -448,15 +457,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                     for (int b = 0; b < 6; b++) {
                         const int c = tileZ[b * kZStride + lane];
                         dst[b * 64] = (int16_t)c;
-                        count_block4(c, lane, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
+                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
                     }
                     count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
-                }
-                // -- the six DC terms, one lane each
-                if (lane < 6) {
-                    const int dc = quant_dc((int)tileZ[lane * kZStride]);
-                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
-                    L.dcw[mbe * 6 + lane] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
                 }
                 wave_sync();   // tileZ is the next iteration's pixel tile
             }
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                     for (int b = 0; b < 6; b++) {
                         const int c = cnext;
                         if (b < 5) cnext = src[(b + 1) * 64];
-                        count_block4(c, lane, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
+                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
                     }
                     count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
                 }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 int cnext = src[0];
 #pragma unroll 1
                 for (int b = 0; b < 6; b++) {
-                    const int c = lane == 0 ? 0 : cnext;       // the DC term is not an AC level (its raw quotient would not fit 12 bits)
+                    const int c = cnext;                       // scan position 0 holds 0 in the slab (the DC term lives in dcw)
                     if (b < 5) cnext = src[(b + 1) * 64];
                     const int q = quant_mag((float)(2 * (c < 0 ? -c : c)), inv1, bias1);     // <= 2048
                     const uint64_t m = wave::ballot(q != 0) | 1ull;
