@@ -568,7 +568,11 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     }
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
-    psxhip_adpcm_session* s = new psxhip_adpcm_session();
+    struct Guard {                       // frees the half-built session on every early return
+        psxhip_adpcm_session* p;
+        ~Guard() { delete p; }
+    } guard{new psxhip_adpcm_session()};
+    psxhip_adpcm_session* s = guard.p;
     s->device = device;
     s->n_chains = n_chains;
     s->speculated = false;
@@ -603,7 +607,6 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     if (e == hipSuccess) e = s->d_changed.alloc(sizeof(int));
     if (e != hipSuccess) {
         psxhip_set_error("adpcm_session_create: hipMalloc failed: %s", hipGetErrorString(e));
-        delete s;
         return PSXHIP_ENOMEM;
     }
     hipStream_t st = s->stream;
@@ -638,6 +641,7 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     job.start_used = s->d_used.as<psxhip_adpcm_state_t>();
     job.units = d_units;
     job.changed = s->d_changed.as<int>();
+    guard.p = nullptr;                   // ownership passes to the caller
     *out = s;
     return PSXHIP_OK;
 }

@@ -21,6 +21,9 @@ namespace {
         }                                                                                     \
     } while (0)
 
+// streams at least this long are also split along time (psxhip_adpcm_encode_chains_chunked)
+constexpr int kChunkedThreshold = 4096, kChunkUnits = 128, kWarmupUnits = 32;
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -72,9 +75,17 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     HIP_TRY(hipMemcpyAsync(d_c.p, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_st.p, states, n_streams * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
-    rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
-                                           n_streams, 5, 4, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
-    if (rc) return rc;
+    if (n_units >= kChunkedThreshold) {
+        // long streams: parallel along time as well (speculate-and-verify; same bytes as the serial chain kernel)
+        HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+        rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), n_streams, 5, 4,
+                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), kChunkUnits, kWarmupUnits, 0, st);
+        if (rc < 0) return rc;
+    } else {
+        rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
+                                               n_streams, 5, 4, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
+        if (rc) return rc;
+    }
     rc = psxhip_spu_pack_device(device, d_u.as<uint8_t>(), n_streams * n_units, d_o.as<uint8_t>(), st);
     if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride, d_o.p, (size_t)bytes, (size_t)bytes, (size_t)n_streams,
@@ -145,9 +156,16 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
     HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_st.p, states, chains.size() * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_e.p, eof.data(), eof.size(), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
-    rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
-                                           (int)chains.size(), 4, bits, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
-    if (rc) return rc;
+    if (units_per_chain >= kChunkedThreshold) {
+        HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+        rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), (int)chains.size(), 4, bits,
+                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), kChunkUnits, kWarmupUnits, 0, st);
+        if (rc < 0) return rc;
+    } else {
+        rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
+                                               (int)chains.size(), 4, bits, d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), st);
+        if (rc) return rc;
+    }
     for (int i = 0; i < n_streams; i++) {
         rc = psxhip_xa_assemble_device(device, d_u.as<uint8_t>() + (size_t)i * units_per_stream * PSXHIP_ADPCM_RECORD_BYTES,
                                        sectors, format, stereo, frequency, bits, file_number, channel_number,

@@ -295,3 +295,37 @@ def test_time_sharded_sessions_simulated_ranks():
         assert final[c].tolist() == [wst.prev1, wst.prev2]
     for s in sessions:
         s.close()
+
+
+def test_long_host_stream_takes_the_chunked_path_and_matches():
+    """psxhip_spu_encode_streams_host switches to speculate-and-verify for streams >= 4096 units"""
+    from psxavenc_amd import adpcm
+    n = 28 * 6000 + 11
+    pcm = np.stack([O.synth_pcm(31, c, 0, n, c) for c in (0, 2)])
+    st = np.array([[10, 20], [-30, 40]], np.int32)
+    st0 = st.copy()
+    out = adpcm.spu_encode_streams(pcm, states=st)
+    for c in range(2):
+        want, wst = O.spu_encode(pcm[c], state=O.Chan(int(st0[c, 0]), int(st0[c, 1])))
+        assert np.array_equal(out[c], want), c
+        assert st[c].tolist() == [wst.prev1, wst.prev2]
+    # XA, long
+    s = adpcm.XaSettings(0, True, 18900, 4, 0, 0)
+    ns = 2016 * 300
+    x = stereo_pad(0, ns, 3, pad=0)
+    got = adpcm.xa_encode_streams(s, x.reshape(1, -1), ns, lbas=[7])[0]
+    want, _ = O.xa_encode(O.XaSettings(0, 1, 18900, 4, 0, 0), np.concatenate([x, np.zeros(8064, np.int16)]), ns, lba=7)
+    assert np.array_equal(got, want)
+
+
+def test_empty_and_tiny_inputs():
+    """edge cases: zero streams / zero samples return empty results; a single sample still yields one block"""
+    from psxavenc_amd import adpcm
+    assert adpcm.spu_encode_streams(np.zeros((1, 0), np.int16)).shape == (1, 0)
+    one = adpcm.spu_encode_streams(np.array([[1234]], np.int16))
+    want, _ = O.spu_encode(np.array([1234], np.int16))
+    assert np.array_equal(one[0], want)
+    s = adpcm.XaSettings(1, False, 37800, 8, 0, 0)
+    got = adpcm.xa_encode_streams(s, np.array([[5, -5, 7]], np.int16), 3)[0]
+    want, _ = O.xa_encode(O.XaSettings(1, 0, 37800, 8, 0, 0), np.concatenate([np.array([5, -5, 7], np.int16), np.zeros(5000, np.int16)]), 3)
+    assert np.array_equal(got, want)

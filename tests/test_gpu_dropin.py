@@ -180,3 +180,35 @@ def test_encode_file_spu_config(L):
     buf = np.zeros(13000, np.uint8)
     ln = L.psx_audio_spu_encode_simple(sine.ctypes.data, sine.size, buf.ctypes.data, -1)
     assert ln == 12624 and np.array_equal(buf[:ln - 16], got[16:16 + ln - 16])
+
+
+def test_c_example_program_builds_runs_and_matches_oracle(tmp_path):
+    """examples/sbs_encode.c: a plain-C host program over the drop-in + batched surfaces (gcc only, no HIP headers)"""
+    import os
+    import subprocess
+    root = O.ROOT
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "examples")], check=True)
+    out = tmp_path / "t.sbs"
+    r = subprocess.run([os.path.join(root, "examples", "sbs_encode"), str(out), "5", "320", "240", "8192", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical to per-frame path: yes" in r.stdout
+    data = np.fromfile(out, dtype=np.uint8).reshape(5, 8192)
+    # regenerate the program's frames (integer ramp + LCG) and diff against the oracle
+    w, h = 320, 240
+    frames = np.zeros((5, w * h * 3 // 2), np.uint8)
+    for i in range(5):
+        lcg = (12345 + 977 * i) & 0xFFFFFFFF
+        yy = np.zeros((h, w), np.int64)
+        for y in range(h):
+            for x in range(w):
+                lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+                yy[y, x] = ((x + 2 * i) % w) * 255 // w // 2 + y * 255 // h // 2 + ((lcg >> 24) % 9) - 4
+        frames[i, :w * h] = np.clip(yy, 0, 255).astype(np.uint8).ravel()
+        c = frames[i, w * h:].reshape(h // 2, w)
+        xs = np.arange(w // 2)
+        ys = np.arange(h // 2)
+        c[:, 0::2] = (96 + xs * 64 // (w // 2)).astype(np.uint8)[None, :]
+        c[:, 1::2] = (160 - ys * 64 // (h // 2)).astype(np.uint8)[:, None]
+    want, _, rc = O.mdec_encode(1, w, h, frames, 8192)
+    assert rc == 0 and np.array_equal(data, want)
