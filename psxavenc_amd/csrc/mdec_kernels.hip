@@ -29,10 +29,10 @@
 
 namespace {
 
-constexpr int kWavesPerGroup = 16;
+constexpr int kWavesPerGroup = 12;
 constexpr int kThreads = kWavesPerGroup * 64;
 constexpr int kScalesPerPass = 4;
-constexpr int kWavesPerSimd = 8;    // occupancy target: two 16-wave workgroups (frames) per CU
+constexpr int kWavesPerSimd = 6;    // occupancy target: two 16-wave workgroups (frames) per CU
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
 constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
 
@@ -244,36 +244,70 @@ __device__ __forceinline__ int lut_index(int q, int run) {
 
 // AC bits of one block at the four scales of a pass; two 16-bit counters per accumulator register.
 // (the DC slot of every block is stored as 0, so lane 0 never produces a level)
-__device__ __forceinline__ void count_block4(int c, const float2& k0, const float2& k1, const float2& k2,
-                                             const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
-                                             int& acc23) {
-    static_assert(kScalesPerPass == 4, "count_block4 evaluates 4 scales");
-    const float two_abs = (float)(2 * (c < 0 ? -c : c));
-    const int q0 = quant_mag(two_abs, k0.x, k0.y);
-    const int q1 = quant_mag(two_abs, k1.x, k1.y);
-    const int q2 = quant_mag(two_abs, k2.x, k2.y);
-    const int q3 = quant_mag(two_abs, k3.x, k3.y);
-    const int i0 = lut_index(q0, run_before(wave::ballot(q0 != 0), lc));
-    const int i1 = lut_index(q1, run_before(wave::ballot(q1 != 0), lc));
-    const int i2 = lut_index(q2, run_before(wave::ballot(q2 != 0), lc));
-    const int i3 = lut_index(q3, run_before(wave::ballot(q3 != 0), lc));
-    acc01 += (int)ac_len[i0] | ((int)ac_len[i1] << 16);
-    acc23 += (int)ac_len[i2] | ((int)ac_len[i3] << 16);
+// `live` (wave-uniform) has bit s set while scale s of the pass can still fit: like the reference, which stops an
+// attempt at the first overflow (mdec.c:323-325,689-706), a scale whose running frame total already exceeds the budget
+// is not evaluated any further -- its verdict cannot change.
+template <int LIVE>
+__device__ __forceinline__ void count_block4_live(float two_abs, const float2& k0, const float2& k1, const float2& k2,
+                                                  const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
+                                                  int& acc23) {
+    // straight-line code for one set of live scales: the compiler interleaves the independent chains
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    if (LIVE & 1) { const int q = quant_mag(two_abs, k0.x, k0.y); i0 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
+    if (LIVE & 2) { const int q = quant_mag(two_abs, k1.x, k1.y); i1 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
+    if (LIVE & 4) { const int q = quant_mag(two_abs, k2.x, k2.y); i2 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
+    if (LIVE & 8) { const int q = quant_mag(two_abs, k3.x, k3.y); i3 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
+    int a01 = 0, a23 = 0;
+    if (LIVE & 1) a01 = (int)ac_len[i0];
+    if (LIVE & 2) a01 |= (int)ac_len[i1] << 16;
+    if (LIVE & 4) a23 = (int)ac_len[i2];
+    if (LIVE & 8) a23 |= (int)ac_len[i3] << 16;
+    if (LIVE & 3) acc01 += a01;
+    if (LIVE & 12) acc23 += a23;
 }
 
-// per-macroblock sums of the packed counters -> LDS, and into the wavefront's running totals
-__device__ __forceinline__ void count_finish4(int acc01, int acc23, int lane, uint16_t* mb_bits_slot, int (&wave_tot)[kScalesPerPass]) {
+__device__ __forceinline__ void count_block4(int c, const float2& k0, const float2& k1, const float2& k2,
+                                             const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int live,
+                                             int& acc01, int& acc23) {
+    static_assert(kScalesPerPass == 4, "count_block4 evaluates 4 scales");
+    const float two_abs = (float)(2 * (c < 0 ? -c : c));
+    // bits(s) falls with s on ordinary material, so scales die lowest-first: those sets get straight-line code
+    switch (live) {
+    case 0xF: count_block4_live<0xF>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
+    case 0xE: count_block4_live<0xE>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
+    case 0xC: count_block4_live<0xC>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
+    case 0x8: count_block4_live<0x8>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
+    case 0x0: break;
+    default:
+        if (live & 1) count_block4_live<1>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
+        if (live & 2) count_block4_live<2>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
+        if (live & 4) count_block4_live<4>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
+        if (live & 8) count_block4_live<8>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
+        break;
+    }
+}
+
+// which scales of the pass are still below the AC-bit limit (wave-uniform bit mask)
+__device__ __forceinline__ int live_scales(const int4& totals, int limit_ac) {
+    static_assert(kScalesPerPass == 4, "one int4 of running totals");
+    const int p0 = __builtin_amdgcn_readfirstlane(totals.x), p1 = __builtin_amdgcn_readfirstlane(totals.y);
+    const int p2 = __builtin_amdgcn_readfirstlane(totals.z), p3 = __builtin_amdgcn_readfirstlane(totals.w);
+    return (p0 <= limit_ac ? 1 : 0) | (p1 <= limit_ac ? 2 : 0) | (p2 <= limit_ac ? 4 : 0) | (p3 <= limit_ac ? 8 : 0);
+}
+
+// per-macroblock sums of the packed counters -> LDS (per macroblock for the offset scan, per frame for rate control)
+__device__ __forceinline__ void count_finish4(int acc01, int acc23, int lane, uint16_t* mb_bits_slot, int* pass_bits) {
     const int t01 = wave::reduce_add(acc01);
     const int t23 = wave::reduce_add(acc23);
-    wave_tot[0] += t01 & 0xFFFF;
-    wave_tot[1] += (unsigned)t01 >> 16;
-    wave_tot[2] += t23 & 0xFFFF;
-    wave_tot[3] += (unsigned)t23 >> 16;
     if (lane == 0) {
         uint2 v;
         v.x = (uint32_t)t01;
         v.y = (uint32_t)t23;
         *(uint2*)mb_bits_slot = v;
+        atomicAdd(&pass_bits[0], t01 & 0xFFFF);
+        atomicAdd(&pass_bits[1], (int)((unsigned)t01 >> 16));
+        atomicAdd(&pass_bits[2], t23 & 0xFFFF);
+        atomicAdd(&pass_bits[3], (int)((unsigned)t23 >> 16));
     }
 }
 
@@ -348,6 +382,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
         const int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
         const int max_words = (max_size + 3) >> 2;
+        // a scale is hopeless once its AC bits alone exceed what the budget leaves after the cheapest possible
+        // DC codes (v2: 10 bits, v3: >= 2 bits), the end-of-block codes and the end-of-frame code:
+        // fits <=> 8 + 2*ceil(bits/16) <= max_size <=> bits <= 16 * floor((max_size - 8) / 2)
+        const int limit_ac = 16 * ((max_size - 8) >> 1) - (nblk * ((CODEC == 0 ? 10 : 2) + 2) + 10);
 
         // ---- reset per-frame state
         for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
@@ -368,9 +406,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             const uint32_t luma_lane = (uint32_t)g_row * (uint32_t)W + (uint32_t)g_c4 * 4u;
             const uint32_t chroma_lane = (uint32_t)W * (uint32_t)H + (uint32_t)(g_row & 7) * (uint32_t)W + (uint32_t)g_c4 * 4u;
             int fy = wid / nx, fx = wid - fy * nx;           // once per frame per wavefront
-            int wave_tot[kScalesPerPass];
-#pragma unroll
-            for (int s_ = 0; s_ < kScalesPerPass; s_++) wave_tot[s_] = 0;
             uint32_t yd = 0, cd = 0;
             if (wid < nmb) {
                 yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
@@ -378,6 +413,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             }
             for (int m = wid; m < nmb; m += kWavesPerGroup) {
                 const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
+                // which scales are still in the race: one 16-byte LDS read, issued early (a slightly stale view only
+                // means a dead scale is evaluated once more)
+                const int4 totals = *(const int4*)L.pass_bits;
 
                 // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
                 {
@@ -453,19 +491,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
                 {
                     const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
                     int acc01 = 0, acc23 = 0;
+                    const int live = live_scales(totals, limit_ac);
 #pragma unroll 1
                     for (int b = 0; b < 6; b++) {
                         const int c = tileZ[b * kZStride + lane];
                         dst[b * 64] = (int16_t)c;
-                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
+                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, live, acc01, acc23);
                     }
-                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
+                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], L.pass_bits);
                 }
                 wave_sync();   // tileZ is the next iteration's pixel tile
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int s_ = 0; s_ < kScalesPerPass; s_++) atomicAdd(&L.pass_bits[s_], wave_tot[s_]);
             }
         }
         __syncthreads();
@@ -551,25 +586,21 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             if (scale0 > 1) {
                 fill_qtab(L.qtab, tid, lane, scale0);
                 __syncthreads();
-                int wave_tot[kScalesPerPass];
-#pragma unroll
-                for (int s_ = 0; s_ < kScalesPerPass; s_++) wave_tot[s_] = 0;
                 for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
                     const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
                     const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
                     int acc01 = 0, acc23 = 0;
+                    const int live = live_scales(*(const int4*)L.pass_bits, limit_ac);
+                    // (kept as a rolled loop with a one-block prefetch: unrolling it costs registers that the
+                    // allocator takes from loop (A))
                     int cnext = src[0];
 #pragma unroll 1
                     for (int b = 0; b < 6; b++) {
                         const int c = cnext;
                         if (b < 5) cnext = src[(b + 1) * 64];
-                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, acc01, acc23);
+                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, live, acc01, acc23);
                     }
-                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], wave_tot);
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int s_ = 0; s_ < kScalesPerPass; s_++) atomicAdd(&L.pass_bits[s_], wave_tot[s_]);
+                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], L.pass_bits);
                 }
                 __syncthreads();
             }
@@ -651,16 +682,29 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
             uint32_t* clist = (uint32_t*)tileT;            // the DCT tiles are idle now: 384 entries fit (kWaveTileBytes >= 1536)
             const uint32_t lane_tag = (uint32_t)lane << 13;
             int nnz = 0;
+            // the six coefficients of this lane are fetched one macroblock ahead (one memory latency per macroblock,
+            // hidden behind the previous macroblock's work)
+            int cn[6];
+            if (wid < nmb) {
+                const int16_t* src = slab + ((unsigned)wid * 384u + (unsigned)lane);
+#pragma unroll
+                for (int b = 0; b < 6; b++) cn[b] = src[b * 64];
+            }
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
+                int cc[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) cc[b] = cn[b];
+                if (mbe + kWavesPerGroup < nmb) {
+                    const int16_t* src = slab + ((unsigned)(mbe + kWavesPerGroup) * 384u + (unsigned)lane);
+#pragma unroll
+                    for (int b = 0; b < 6; b++) cn[b] = src[b * 64];
+                }
                 // ---- 1. compaction.  Entry: [11:0] unclamped |level|, [12] sign, [18:13] scan position.
                 //      Lane 0 (scan position 0) is always kept: it marks the block's DC slot.
                 int count = 0;                             // wave-uniform
-                int cnext = src[0];
-#pragma unroll 1
+#pragma unroll
                 for (int b = 0; b < 6; b++) {
-                    const int c = cnext;                       // scan position 0 holds 0 in the slab (the DC term lives in dcw)
-                    if (b < 5) cnext = src[(b + 1) * 64];
+                    const int c = cc[b];                       // scan position 0 holds 0 in the slab (the DC term lives in dcw)
                     const int q = quant_mag((float)(2 * (c < 0 ? -c : c)), inv1, bias1);     // <= 2048
                     const uint64_t m = wave::ballot(q != 0) | 1ull;
                     if (q != 0 || lane == 0)

@@ -128,8 +128,8 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
     if (const char* e = getenv("PSXHIP_MDEC_TIMING")) {
         if (atoi(e)) {
-            HIP_TRY(hipMalloc((void**)&c->d_timing, 8 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
-            HIP_TRY(hipMemset(c->d_timing, 0, 8 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
+            HIP_TRY(hipMalloc((void**)&c->d_timing, 16 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
+            HIP_TRY(hipMemset(c->d_timing, 0, 16 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
         }
     }
     *out = c;
@@ -264,12 +264,12 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
 
 extern "C" int psxhip_mdec_read_timing(psxhip_mdec_ctx_t* c, unsigned long long* out8, int reset) {
     if (!c || !out8) return PSXHIP_EINVAL;
-    memset(out8, 0, 8 * sizeof(unsigned long long));
+    memset(out8, 0, 16 * sizeof(unsigned long long));
     if (!c->d_timing) return PSXHIP_OK;
     HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
     HIP_TRY(hipDeviceSynchronize(), PSXHIP_EDEVICE);
-    HIP_TRY(hipMemcpy(out8, c->d_timing, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
-    if (reset) HIP_TRY(hipMemset(c->d_timing, 0, 8 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpy(out8, c->d_timing, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
+    if (reset) HIP_TRY(hipMemset(c->d_timing, 0, 16 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
 
