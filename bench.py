@@ -140,10 +140,10 @@ def main():
     # (PMC counters cannot be read from inside the process); the committed summary is quoted when the workload matches
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v3_pmc.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc.json")) as fh:
             pmc = json.load(fh)
         if (args.codec, w, h, budget, n, args.amp) == (0, 320, 240, 8192, 1000, 4):
-            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_v3_pmc.json"
+            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_v4_pmc.json"
     except Exception:
         pass
 
