@@ -29,10 +29,11 @@
 
 namespace {
 
-constexpr int kWavesPerGroup = 12;
-constexpr int kThreads = kWavesPerGroup * 64;
+// Two workgroup shapes: 12 wavefronts at 6 per SIMD (two frames per CU; 80 VGPRs) when two groups' LDS fits one CU,
+// otherwise 16 wavefronts at 4 per SIMD (one frame per CU; 128 VGPRs) -- large frames / large budgets.
+constexpr int kWavesSmall = 12, kOccSmall = 6;
+constexpr int kWavesLarge = 16, kOccLarge = 4;
 constexpr int kScalesPerPass = 4;
-constexpr int kWavesPerSimd = 6;    // occupancy target: two 16-wave workgroups (frames) per CU
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
 constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
 
@@ -165,7 +166,7 @@ struct Lds {
 
 constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile (the pixel tile aliases the latter)
 
-__host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
+__host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int waves) {
     size_t b = 0;
     b += (size_t)out_words * 4;
     b += (size_t)nmb * kScalesPerPass * 2;
@@ -177,13 +178,13 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words) {
     b += BS_LUT_SIZE * 4;         // ac_code
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    b += (size_t)waves * kWaveTileBytes;
     b += (size_t)kScalesPerPass * 64 * 8;   // qtab
     b += 64;                      // pass_bits + scalars
     return b;
 }
 
-__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words) {
+__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int waves) {
     Lds L;
     size_t b = 0;
     L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
@@ -194,7 +195,7 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words) {
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
-    L.tiles = (int16_t*)(base + b);       b += (size_t)kWavesPerGroup * kWaveTileBytes;
+    L.tiles = (int16_t*)(base + b);       b += (size_t)waves * kWaveTileBytes;
     L.qtab = (float2*)(base + b);         b += (size_t)kScalesPerPass * 64 * 8;
     L.pass_bits = (int*)(base + b);       b += kScalesPerPass * 4;
     L.scalars = (int*)(base + b);
@@ -326,10 +327,12 @@ __device__ __forceinline__ void fill_qtab(float2* qtab, int tid, int lane, int s
 // that would need > 64 registers.  The three per-macroblock loops are: (A) DCT -> slab, (B) bit counts
 // for kScalesPerPass scales from the slab, (C) emit at the chosen scale from the slab.
 // ---------------------------------------------------------------------------------------------
-template <int CODEC>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_kernel(const FrameJob job) {
+template <int CODEC, int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(const FrameJob job) {
+    constexpr int kWavesPerGroup = WAVES;
+    constexpr int kThreads = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds L = carve(smem, job.nmb, job.out_words);
+    const Lds L = carve(smem, job.nmb, job.out_words, WAVES);
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -808,9 +811,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mdec_encode_frames_ke
 // ---------------------------------------------------------------------------------------------
 // Host side of the kernel (called from psxhip_mdec.cpp through psxhip_internal.h)
 // ---------------------------------------------------------------------------------------------
-extern "C" size_t psxhip_mdec_lds_bytes(int nmb, int out_words) { return lds_bytes(nmb, out_words); }
+extern "C" size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int large) {
+    return lds_bytes(nmb, out_words, large ? kWavesLarge : kWavesSmall);
+}
 extern "C" size_t psxhip_mdec_slab_bytes_per_group(int nmb) { return (size_t)nmb * 384 * sizeof(int16_t); }
-extern "C" int psxhip_mdec_threads_per_group(void) { return kThreads; }
+extern "C" int psxhip_mdec_threads_per_group(int large) { return (large ? kWavesLarge : kWavesSmall) * 64; }
 
 extern "C" hipError_t psxhip_mdec_upload_tables(void) {
     hipError_t e;
@@ -846,21 +851,39 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.coef_slab = a->d_coef_slab;
     job.out_words = a->out_words;
     job.timing = a->d_timing;
-    const size_t lds = lds_bytes(job.nmb, job.out_words);
-    const dim3 grid((unsigned)a->grid), block(kThreads);
+    const int waves = a->large ? kWavesLarge : kWavesSmall;
+    const size_t lds = lds_bytes(job.nmb, job.out_words, waves);
+    const dim3 grid((unsigned)a->grid), block((unsigned)waves * 64u);
     hipStream_t st = (hipStream_t)a->stream;
+#define PSX_LAUNCH(CODEC)                                                                                             \
+    do {                                                                                                              \
+        if (a->large) hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge>), grid, block, lds, st, job); \
+        else hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall>), grid, block, lds, st, job);          \
+    } while (0)
     switch (a->codec) {
-    case 0: hipLaunchKernelGGL(mdec_encode_frames_kernel<0>, grid, block, lds, st, job); break;
-    case 1: hipLaunchKernelGGL(mdec_encode_frames_kernel<1>, grid, block, lds, st, job); break;
-    default: hipLaunchKernelGGL(mdec_encode_frames_kernel<2>, grid, block, lds, st, job); break;
+    case 0: PSX_LAUNCH(0); break;
+    case 1: PSX_LAUNCH(1); break;
+    default: PSX_LAUNCH(2); break;
     }
+#undef PSX_LAUNCH
     return hipGetLastError();
 }
 
 extern "C" hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes) {
+    hipError_t e = hipSuccess;
+#define PSX_ATTR(CODEC)                                                                                                         \
+    do {                                                                                                                        \
+        e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                        \
+        if (e == hipSuccess)                                                                                                    \
+            e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge>,                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                    \
+    } while (0)
     switch (codec) {
-    case 0: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    case 1: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    default: return hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    case 0: PSX_ATTR(0); break;
+    case 1: PSX_ATTR(1); break;
+    default: PSX_ATTR(2); break;
     }
+#undef PSX_ATTR
+    return e;
 }

@@ -71,6 +71,7 @@ struct psxhip_mdec_ctx {
     int device, codec, width, height, nmb;
     int max_frame_size, out_words;
     int groups_max;            // persistent grid size: compute units x resident groups per CU
+    int large;                 // 1: one 16-wavefront group per CU (two 12-wavefront groups do not fit the LDS)
     size_t lds_bytes;
     int16_t* d_slab;
     unsigned long long* d_timing;   // diagnostics (PSXHIP_MDEC_TIMING=1)
@@ -105,23 +106,21 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     c->nmb = (width / 16) * (height / 16);
     c->max_frame_size = max_frame_size;
     c->out_words = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
-    c->lds_bytes = psxhip_mdec_lds_bytes(c->nmb, c->out_words);
-
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
-    if (c->lds_bytes > (size_t)prop.maxSharedMemoryPerMultiProcessor) {
+    const size_t lds_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+    // shape: two 12-wavefront groups per CU when their LDS fits, else one 16-wavefront group
+    c->large = 2 * psxhip_mdec_lds_bytes(c->nmb, c->out_words, 0) > lds_cu;
+    c->lds_bytes = psxhip_mdec_lds_bytes(c->nmb, c->out_words, c->large);
+    if (c->lds_bytes > lds_cu) {
         psxhip_set_error("frame budget %d with %d macroblocks needs %zu B of LDS (> %zu)", max_frame_size, c->nmb,
-                         c->lds_bytes, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+                         c->lds_bytes, lds_cu);
         free(c);
         return PSXHIP_EINVAL;
     }
-    // opt the kernel into the whole LDS once (contexts with different geometries share the kernel attribute)
-    HIP_TRY(psxhip_mdec_set_max_lds(codec, (size_t)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
-    int per_cu = (int)((size_t)prop.maxSharedMemoryPerMultiProcessor / c->lds_bytes);
-    const int by_threads = prop.maxThreadsPerMultiProcessor / psxhip_mdec_threads_per_group();
-    if (per_cu > by_threads) per_cu = by_threads;
-    if (per_cu < 1) per_cu = 1;
-    c->groups_max = prop.multiProcessorCount * per_cu;
+    // opt the kernels into the whole LDS once (contexts with different geometries share the kernel attribute)
+    HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
+    c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
 
     const size_t slab = psxhip_mdec_slab_bytes_per_group(c->nmb) * (size_t)c->groups_max;
     HIP_TRY(hipMalloc((void**)&c->d_slab, slab), PSXHIP_ENOMEM);
@@ -187,6 +186,7 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.d_coef_slab = c->d_slab;
     a.out_words = c->out_words;
     a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
+    a.large = c->large;
     a.stream = stream;
     a.d_timing = c->d_timing;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);

@@ -23,13 +23,14 @@ typedef struct {
 	int16_t *d_coef_slab;
 	int out_words;
 	int grid;
+	int large;   /* 1: 16-wavefront groups, one per CU (large frames / budgets) */
 	void *stream;
 	unsigned long long *d_timing;
 } psxhip_mdec_launch_t;
 
-size_t psxhip_mdec_lds_bytes(int nmb, int out_words);
+size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int large);
 size_t psxhip_mdec_slab_bytes_per_group(int nmb);
-int psxhip_mdec_threads_per_group(void);
+int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
