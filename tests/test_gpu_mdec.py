@@ -225,3 +225,54 @@ def test_two_contexts_with_different_lds_needs_coexist():
     assert_same(out_s, r_s, want_s, res_s, "48x32")
     big.close()
     small.close()
+
+
+def test_randomised_geometry_content_budgets_vs_oracle():
+    """seeded fuzz: random sizes (multiples of 16 up to 128x96), codecs, per-frame budgets (odd ones too) and content
+    mixes -- smooth ramps, noise of random amplitude, random flat 8x8 tiles (DC ties / big DC swings), sparse impulses
+    (long zero runs -> run-length escapes).  Frames that fit no scale must be reported, everything else byte-exact."""
+    from psxavenc_amd import _lib
+    rng = np.random.default_rng(20260928)
+    n_cases, n_nofit = 0, 0
+    for case in range(60):
+        w, h = 16 * int(rng.integers(1, 9)), 16 * int(rng.integers(1, 7))
+        codec = int(rng.integers(0, 3))
+        n = int(rng.integers(1, 6))
+        npx = w * h
+        frames = np.zeros((n, npx * 3 // 2), np.uint8)
+        for k in range(n):
+            kind = int(rng.integers(0, 4))
+            yy, xx = np.mgrid[0:h, 0:w]
+            if kind == 0:
+                y = (xx * int(rng.integers(0, 4)) + yy * int(rng.integers(0, 4))) % 256 + rng.integers(-3, 4, (h, w))
+            elif kind == 1:
+                y = 128 + rng.integers(-int(rng.integers(1, 60)), int(rng.integers(1, 60)) + 1, (h, w))
+            elif kind == 2:
+                tiles = rng.integers(0, 256, (h // 8, w // 8))
+                y = np.kron(tiles, np.ones((8, 8), np.int64))
+            else:
+                y = np.full((h, w), int(rng.integers(0, 256)))
+                for _ in range(int(rng.integers(1, 12))):
+                    y[int(rng.integers(0, h)), int(rng.integers(0, w))] = int(rng.integers(0, 256))
+            frames[k, :npx] = np.clip(y, 0, 255).astype(np.uint8).ravel()
+            frames[k, npx:] = np.clip(128 + rng.integers(-int(rng.integers(1, 40)), int(rng.integers(1, 40)) + 1, npx // 2), 0, 255).astype(np.uint8)
+        nblk = (w // 16) * (h // 16) * 6
+        floor_bytes = 8 + 2 * ((nblk * 12 + 10 + 15) // 16)
+        budgets = rng.integers(floor_bytes, floor_bytes + int(rng.integers(16, 6000)), n).astype(np.int32)
+        if case % 10 == 0:
+            budgets[0] = floor_bytes - 2        # below the floor of 12 bits per block: no scale can fit
+        enc = encoder(codec, w, h, int(budgets.max()))
+        for k in range(n):
+            want, want_res, rc = O.mdec_encode(codec, w, h, frames[k:k + 1], int(budgets[k]))
+            if rc == 0:
+                out, res = enc.encode_frames_host(frames[k:k + 1], int(budgets[k]))
+                assert_same(out, res, want, want_res, "fuzz case %d frame %d (%dx%d codec %d budget %d)" % (case, k, w, h, codec, budgets[k]))
+                n_cases += 1
+            else:
+                assert rc == -2
+                with pytest.raises(_lib.PsxHipError) as e:
+                    enc.encode_frames_host(frames[k:k + 1], int(budgets[k]))
+                assert e.value.code == _lib.PSXHIP_ENOFIT
+                n_nofit += 1
+        enc.close()
+    assert n_cases > 80 and n_nofit > 0
