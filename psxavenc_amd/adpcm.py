@@ -247,6 +247,16 @@ def xa_assemble_device(d_units, n_sectors, settings, first_lba=0, d_eof=None):
     return out
 
 
+def pick_chunking(total_units):
+    """(chunk_units, warmup_units) for speculate-and-verify: few verify passes vs enough chunks to fill the GPU
+    (same rule as psxhip_audio_api.cpp; tools/gpu_adpcm_sweep.py)."""
+    c = total_units // 16384
+    p = 64
+    while p * 2 <= c and p < 1024:
+        p *= 2
+    return p, min(64, max(16, p // 8))
+
+
 class AdpcmSession:
     """psxhip_adpcm_session_* (include/psxav_hip.h): a persistent speculate-and-verify encode of a set of chains, whose
     start states can be corrected later (time-sharding across GPUs, psxavenc_amd/parallel.py)."""

@@ -22,7 +22,18 @@ namespace {
     } while (0)
 
 // streams at least this long are also split along time (psxhip_adpcm_encode_chains_chunked)
-constexpr int kChunkedThreshold = 4096, kChunkUnits = 128, kWarmupUnits = 32;
+constexpr int kChunkedThreshold = 4096;
+
+// chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass), short enough
+// that there are >= ~16 k chunks to fill 256 CUs (tools/gpu_adpcm_sweep.py); warm-up = chunk / 8
+inline void pick_chunking(long long total_units, int* chunk_units, int* warmup_units) {
+    long long c = total_units / 16384;
+    int p = 64;
+    while (p * 2 <= c && p < 1024) p *= 2;
+    *chunk_units = p;
+    int w = p / 8;
+    *warmup_units = w < 16 ? 16 : (w > 64 ? 64 : w);
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -78,8 +89,10 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     if (n_units >= kChunkedThreshold) {
         // long streams: parallel along time as well (speculate-and-verify; same bytes as the serial chain kernel)
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+        int chunk_units, warmup_units;
+        pick_chunking((long long)n_units * n_streams, &chunk_units, &warmup_units);
         rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), n_streams, 5, 4,
-                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), kChunkUnits, kWarmupUnits, 0, st);
+                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), chunk_units, warmup_units, 0, st);
         if (rc < 0) return rc;
     } else {
         rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),
@@ -158,8 +171,10 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
     HIP_TRY(hipMemcpyAsync(d_e.p, eof.data(), eof.size(), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     if (units_per_chain >= kChunkedThreshold) {
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
+        int chunk_units, warmup_units;
+        pick_chunking((long long)units_per_chain * (long long)chains.size(), &chunk_units, &warmup_units);
         rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), (int)chains.size(), 4, bits,
-                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), kChunkUnits, kWarmupUnits, 0, st);
+                                                d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), chunk_units, warmup_units, 0, st);
         if (rc < 0) return rc;
     } else {
         rc = psxhip_adpcm_encode_chains_device(device, d_s.as<int16_t>(), d_c.as<psxhip_adpcm_chain_t>(), d_b.as<int32_t>(),

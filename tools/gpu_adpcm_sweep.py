@@ -1,0 +1,18 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from psxavenc_amd import adpcm, synth
+n_chains, n_units = 16, 810000   # 10 min of 37800 Hz per chain... (28 samples per unit): 37800*600/28
+n = n_units * 28
+d = torch.empty((n_chains, n), dtype=torch.int16, device="cuda:0")
+for kind in (0, 2):
+    for c in range(n_chains):
+        synth.pcm_device(5, c, 0, n, kind, out=d[c])
+    chains = adpcm.make_chains(np.arange(n_chains) * n, 1, n, n_units)
+    base = np.arange(n_chains, dtype=np.int32) * n_units
+    for chunk, warm in ((128, 32), (256, 32), (256, 64), (512, 64), (1024, 64), (2048, 128)):
+        adpcm.encode_chains_device(d.reshape(-1), chains, base, 4, 4, chunk_units=chunk, warmup_units=warm)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        u, s, passes = adpcm.encode_chains_device(d.reshape(-1), chains, base, 4, 4, chunk_units=chunk, warmup_units=warm)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print("kind %d chunk %4d warm %3d: %7.1f ms, %2d passes, %.0f Munits/s" % (kind, chunk, warm, dt * 1e3, passes, n_chains * n_units / dt / 1e6))
