@@ -374,8 +374,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
 
     int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
     int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
-    uint32_t* pix32 = (uint32_t*)tileZ;                                // [6][8][2] dwords of source pixels (aliases tileZ)
-    uint16_t* pix16 = (uint16_t*)tileZ;
 
     int16_t* slab = job.coef_slab + (size_t)blockIdx.x * nmb * 384;
 
@@ -403,16 +401,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         //     count pass (scales 1..kScalesPerPass) while the coefficients are still in LDS
         // =====================================================================================
         {
-            // source bytes of a macroblock (mdec.c:619-633); NV21: Cr at even bytes, Cb at odd
-            const int g_row = lane >> 2, g_c4 = lane & 3;
-            // all offsets are 32-bit (a frame is < 2^31 bytes); (fx, fy) advance incrementally, no divisions
-            const uint32_t luma_lane = (uint32_t)g_row * (uint32_t)W + (uint32_t)g_c4 * 4u;
-            const uint32_t chroma_lane = (uint32_t)W * (uint32_t)H + (uint32_t)(g_row & 7) * (uint32_t)W + (uint32_t)g_c4 * 4u;
-            int fy = wid / nx, fx = wid - fy * nx;           // once per frame per wavefront
-            uint32_t yd = 0, cd = 0;
+            // Source bytes of a macroblock (mdec.c:619-633).  Lane t < 48 = (block t>>3, row t&7) fetches its own
+            // 8 pixels straight from the frame (no LDS staging): a luma row is 8 contiguous bytes, a chroma row is
+            // 16 bytes of interleaved Cr,Cb (NV21: Cr at even bytes, Cb at odd).  All offsets are 32-bit (a frame is
+            // < 2^31 bytes); (fx, fy) advance incrementally, no divisions.
+            const int blk = lane >> 3, r8 = lane & 7;
+            const bool is_chroma = blk < 2;
+            uint32_t lane_off;      // offset of this lane's pixel row inside macroblock (0, 0)
+            if (is_chroma) lane_off = (uint32_t)W * (uint32_t)H + (uint32_t)r8 * (uint32_t)W;
+            else lane_off = ((uint32_t)(((blk - 2) >> 1) * 8 + r8)) * (uint32_t)W + (uint32_t)((blk - 2) & 1) * 8u;
+            if (lane >= 48) lane_off = 0;                       // idle lanes read the frame's first bytes (unused)
+            const uint32_t hi_off = is_chroma ? 8u : 0u;        // chroma rows are 16 bytes long
+            const uint32_t mb_row_step = (is_chroma ? 8u : 16u) * (uint32_t)W;
+            const uint32_t perm_sel = blk == 0 ? 0x06040200u : 0x07050301u;   // even (Cr) / odd (Cb) bytes of a dword pair
+            int fy = wid / nx, fx = wid - fy * nx;              // once per frame per wavefront
+            uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
             if (wid < nmb) {
-                yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
-                cd = *(const uint32_t*)(frame + (chroma_lane + (uint32_t)fy * 8u * (uint32_t)W + (uint32_t)fx * 16u));   // lanes >= 32 re-read rows 0..7 (unused)
+                const uint8_t* p = frame + (lane_off + (uint32_t)fy * mb_row_step + (uint32_t)fx * 16u);
+                plo = *(const uint2*)p;
+                phi = *(const uint2*)(p + hi_off);
             }
             for (int m = wid; m < nmb; m += kWavesPerGroup) {
                 const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
@@ -420,41 +427,32 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // means a dead scale is evaluated once more)
                 const int4 totals = *(const int4*)L.pass_bits;
 
-                // -- re-tile the macroblock's 384 source bytes into six 8x8 blocks in LDS
-                {
-                    const int blk = 2 + ((g_row >> 3) << 1) + (g_c4 >> 1);
-                    pix32[(blk * 8 + (g_row & 7)) * 2 + (g_c4 & 1)] = yd;
-                    if (lane < 32) {
-                        const uint32_t cr = (cd & 0xFFu) | ((cd >> 8) & 0xFF00u);
-                        const uint32_t cb = ((cd >> 8) & 0xFFu) | ((cd >> 16) & 0xFF00u);
-                        pix16[(0 * 8 + g_row) * 4 + g_c4] = (uint16_t)cr;
-                        pix16[(1 * 8 + g_row) * 4 + g_c4] = (uint16_t)cb;
-                    }
-                }
-                wave_sync();
+                // -- this lane's 8 pixels as two dwords
+                uint2 px;
+                px.x = is_chroma ? __builtin_amdgcn_perm(plo.y, plo.x, perm_sel) : plo.x;
+                px.y = is_chroma ? __builtin_amdgcn_perm(phi.y, phi.x, perm_sel) : plo.y;
                 // -- prefetch the next macroblock of this wavefront while this one is transformed
                 {
                     fx += kWavesPerGroup;
                     while (fx >= nx) { fx -= nx; fy++; }
                     if (m + kWavesPerGroup < nmb) {
-                        yd = *(const uint32_t*)(frame + (luma_lane + (uint32_t)fy * 16u * (uint32_t)W + (uint32_t)fx * 16u));
-                        cd = *(const uint32_t*)(frame + (chroma_lane + (uint32_t)fy * 8u * (uint32_t)W + (uint32_t)fx * 16u));
+                        const uint8_t* p = frame + (lane_off + (uint32_t)fy * mb_row_step + (uint32_t)fx * 16u);
+                        plo = *(const uint2*)p;
+                        phi = *(const uint2*)(p + hi_off);
                     }
                 }
 
-                const int blk = lane >> 3, r8 = lane & 7;
                 int d[8];
                 if (lane < 48) {
                     // -- row pass: lane = (block, row)
-                    const uint2 p = *(const uint2*)&pix32[(blk * 8 + r8) * 2];
-                    d[0] = (int)(p.x & 0xFF) - 128;
-                    d[1] = (int)((p.x >> 8) & 0xFF) - 128;
-                    d[2] = (int)((p.x >> 16) & 0xFF) - 128;
-                    d[3] = (int)(p.x >> 24) - 128;
-                    d[4] = (int)(p.y & 0xFF) - 128;
-                    d[5] = (int)((p.y >> 8) & 0xFF) - 128;
-                    d[6] = (int)((p.y >> 16) & 0xFF) - 128;
-                    d[7] = (int)(p.y >> 24) - 128;
+                    d[0] = (int)(px.x & 0xFF) - 128;
+                    d[1] = (int)((px.x >> 8) & 0xFF) - 128;
+                    d[2] = (int)((px.x >> 16) & 0xFF) - 128;
+                    d[3] = (int)(px.x >> 24) - 128;
+                    d[4] = (int)(px.y & 0xFF) - 128;
+                    d[5] = (int)((px.y >> 8) & 0xFF) - 128;
+                    d[6] = (int)((px.y >> 16) & 0xFF) - 128;
+                    d[7] = (int)(px.y >> 24) - 128;
                     fdct8<false>(d);
 #pragma unroll
                     for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
@@ -472,21 +470,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     d[6] = (int)(int16_t)(q.w & 0xFFFF);
                     d[7] = q.w >> 16;
                     fdct8<true>(d);
+                    // -- column 0 holds the block's DC term in d[0]: quantise it here, and store 0 in its place so that
+                    //    the AC path (here, in later count passes and in emit) sees "no coefficient" at scan position 0
+                    if (r8 == 0) {
+                        const int dc = quant_dc(d[0]);
+                        // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
+                        L.dcw[mbe * 6 + blk] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                        d[0] = 0;
+                    }
 #pragma unroll
                     for (int v = 0; v < 8; v++) {
                         const uint32_t zp = ((v < 4 ? zpos_lo : zpos_hi) >> (8 * (v & 3))) & 0xFFu;
                         tileZ[blk * kZStride + zp] = (int16_t)d[v];
                     }
-                }
-                wave_sync();
-
-                // -- the six DC terms, one lane each; the DC slot is then zeroed so that the AC path (here, in later
-                //    count passes and in emit) sees "no coefficient" at scan position 0 without a per-lane select
-                if (lane < 6) {
-                    const int dc = quant_dc((int)tileZ[lane * kZStride]);
-                    // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
-                    L.dcw[mbe * 6 + lane] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
-                    tileZ[lane * kZStride] = 0;
                 }
                 wave_sync();
                 // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, and counted at scales 1..4
@@ -503,7 +499,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                     count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], L.pass_bits);
                 }
-                wave_sync();   // tileZ is the next iteration's pixel tile
+                wave_sync();   // the zig-zag tile is rewritten by the next iteration
             }
         }
         __syncthreads();
