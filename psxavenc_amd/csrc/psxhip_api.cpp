@@ -99,6 +99,10 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
 
     psxhip_mdec_ctx* c = (psxhip_mdec_ctx*)calloc(1, sizeof(*c));
     if (!c) return PSXHIP_ENOMEM;
+    struct Guard {                       // releases the half-built context on every early return
+        psxhip_mdec_ctx* p;
+        ~Guard() { if (p) psxhip_mdec_destroy(p); }
+    } guard{c};
     c->device = device;
     c->codec = codec;
     c->width = width;
@@ -115,7 +119,6 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     if (c->lds_bytes > lds_cu) {
         psxhip_set_error("frame budget %d with %d macroblocks needs %zu B of LDS (> %zu)", max_frame_size, c->nmb,
                          c->lds_bytes, lds_cu);
-        free(c);
         return PSXHIP_EINVAL;
     }
     // opt the kernels into the whole LDS once (contexts with different geometries share the kernel attribute)
@@ -131,6 +134,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
             HIP_TRY(hipMemset(c->d_timing, 0, 16 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
         }
     }
+    guard.p = nullptr;                   // ownership passes to the caller
     *out = c;
     return PSXHIP_OK;
 }
