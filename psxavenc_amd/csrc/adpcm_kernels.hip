@@ -81,22 +81,25 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
 }
 
 // One sound unit for the 16-lane row this lane belongs to (adpcm.c:142-191 encode()): every lane tries its
-// own (filter, shift) candidate on the 28 samples x[], the row agrees on the winner, and (prev1, prev2)
-// advance to the winner's decoded state when `unit_live`.  Returns true on the winning lane, whose
-// `header` / `packed[7]` then hold the unit's record.
-__device__ __forceinline__ bool encode_unit(const Candidate& cd, const int (&x)[28], bool unit_live, int lane, int& prev1,
-                                            int& prev2, uint32_t& header, uint32_t (&packed)[7]) {
+// own (filter, shift) candidate on the row's 28 samples xs[] (staged in LDS: one broadcast read per step, so
+// the recursion needs a handful of registers and 8 wavefronts fit a SIMD), the row agrees on the winner, and
+// (prev1, prev2) advance to the winner's decoded state when `unit_live`.  Returns true on the winning lane,
+// whose `header` and pk_lds[w * 64 + lane] (w = 0..6: four codes per word) then hold the unit's record.  The trial
+// loop is kept rolled (codes parked in LDS) so that the whole encoder needs few registers.
+__device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, bool unit_live, int lane, int& prev1,
+                                            int& prev2, uint32_t& header, uint32_t* pk_lds /* [7][64] per wavefront */) {
     // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples
     int lo = 0, hi = 0;
     {
         int p1 = prev1, p2 = prev2;
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < 28; i++) {
-            const int r = x[i] - predict(cd.k1, cd.k2, p1, p2);
+            const int xi = xs[i];
+            const int r = xi - predict(cd.k1, cd.k2, p1, p2);
             lo = r < lo ? r : lo;
             hi = r > hi ? r : hi;
             p2 = p1;
-            p1 = x[i];
+            p1 = xi;
         }
     }
     int rs = 0;
@@ -110,14 +113,14 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int (&x)[
     // ---- attempt_to_encode for (filter, shift) (adpcm.c:81-140)
     uint64_t sse = 0;
     int p1 = prev1, p2 = prev2;
-#pragma unroll
+#pragma unroll 1
     for (int w = 0; w < 7; w++) {
         uint32_t pk = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int i = w * 4 + j;
+            const int xi = xs[w * 4 + j];
             const int pred = predict(cd.k1, cd.k2, p1, p2);
-            int q = (int)((uint32_t)(x[i] - pred) << sh);
+            int q = (int)((uint32_t)(xi - pred) << sh);
             q = (q + cd.half) >> cd.range;
             q = q < cd.qmin ? cd.qmin : q;
             q = q > cd.qmax ? cd.qmax : q;
@@ -126,13 +129,13 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int (&x)[
             dec = (dec >> sh) + pred;
             dec = dec > 0x7FFF ? 0x7FFF : dec;
             dec = dec < -0x8000 ? -0x8000 : dec;
-            const int err = dec - x[i];
+            const int err = dec - xi;
             sse += (uint64_t)((int64_t)err * (int64_t)err);
             pk |= (uint32_t)q << (8 * j);
             p2 = p1;
             p1 = dec;
         }
-        packed[w] = pk;
+        pk_lds[w * 64 + lane] = pk;
     }
 
     // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
@@ -151,25 +154,42 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int (&x)[
     return winner;
 }
 
-// the 28 samples of chain-local unit u; samples at chain index >= sample_limit read as zero (adpcm.c:65,110)
-__device__ __forceinline__ void load_unit(const int16_t* src, const psxhip_adpcm_chain_t& ch, int u, bool live, int (&x)[28]) {
-    const int limit = ch.sample_limit - u * 28;
-#pragma unroll
-    for (int i = 0; i < 28; i++) {
-        int v = 0;
-        if (live && i < limit) v = src[(long long)(u * 28 + i) * ch.pitch];
-        x[i] = v;
-    }
+// wave-level ordering point for LDS traffic between lanes of the same wavefront
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void store_record(uint8_t* units, long long index, uint32_t header, const uint32_t (&packed)[7]) {
+// Stage the 28 samples of chain-local unit u of each of the wavefront's four rows into LDS (xs = this row's
+// 32-int buffer): lane c of the row fetches samples c and c + 16.  Samples at chain index >= sample_limit read
+// as zero without touching memory (adpcm.c:65,110).
+struct UnitFetch {
+    int a, b;
+};
+__device__ __forceinline__ UnitFetch fetch_unit(const int16_t* src, const psxhip_adpcm_chain_t& ch, int u, bool live, int lane) {
+    const int c = lane & 15;
+    const int limit = ch.sample_limit - u * 28;
+    UnitFetch f;
+    f.a = (live && c < limit) ? (int)src[(long long)(u * 28 + c) * ch.pitch] : 0;
+    f.b = (live && c + 16 < 28 && c + 16 < limit) ? (int)src[(long long)(u * 28 + c + 16) * ch.pitch] : 0;
+    return f;
+}
+__device__ __forceinline__ void stage_unit(int* xs, const UnitFetch& f, int lane) {
+    const int c = lane & 15;
+    wave_sync();            // the previous unit's readers are done
+    xs[c] = f.a;
+    xs[c + 16] = f.b;       // slots 28..31 are padding
+    wave_sync();
+}
+
+__device__ __forceinline__ void store_record(uint8_t* units, long long index, uint32_t header, const uint32_t* pk_lds, int lane) {
     uint32_t* rec = (uint32_t*)(units + index * kRecordBytes);
     rec[0] = header;
 #pragma unroll
-    for (int w = 0; w < 7; w++) rec[1 + w] = packed[w];
+    for (int w = 0; w < 7; w++) rec[1 + w] = pk_lds[w * 64 + lane];
 }
 
-__global__ __launch_bounds__(64) void adpcm_chains_kernel(const ChainJob job) {
+__global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job) {
     const int lane = (int)(threadIdx.x & 63);
     const int chain = (int)blockIdx.x * 4 + (lane >> 4);
     const bool chain_live = chain < job.n_chains;
@@ -191,14 +211,18 @@ __global__ __launch_bounds__(64) void adpcm_chains_kernel(const ChainJob job) {
     n_max = max(n_max, __shfl_xor(n_max, 32, 64));
 
     const int16_t* src = job.samples + ch.sample_offset;
+    __shared__ int xs_all[4][32];
+    __shared__ uint32_t pk_lds[7 * 64];
+    int* xs = xs_all[lane >> 4];
 
+    UnitFetch nxt = fetch_unit(src, ch, 0, chain_live && 0 < ch.n_units, lane);
     for (int u = 0; u < n_max; u++) {
         const bool unit_live = chain_live && u < ch.n_units;
-        int x[28];
-        load_unit(src, ch, u, unit_live, x);
-        uint32_t header, packed[7];
-        if (encode_unit(cd, x, unit_live, lane, prev1, prev2, header, packed))
-            store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, packed);
+        stage_unit(xs, nxt, lane);
+        if (u + 1 < n_max) nxt = fetch_unit(src, ch, u + 1, chain_live && u + 1 < ch.n_units, lane);   // prefetch
+        uint32_t header;
+        if (encode_unit(cd, xs, unit_live, lane, prev1, prev2, header, pk_lds))
+            store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
     }
     if (chain_live && (lane & 15) == 0) {
         job.states[chain].prev1 = prev1;
@@ -241,7 +265,7 @@ struct ChunkJob {
 };
 
 template <bool VERIFY>
-__global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
+__global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job) {
     const int lane = (int)(threadIdx.x & 63);
     const int chunk = (int)blockIdx.x * 4 + (lane >> 4);
     const bool chunk_live = chunk < job.n_chunks;
@@ -290,12 +314,14 @@ __global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
     int w_max = n_warm;
     w_max = max(w_max, __shfl_xor(w_max, 16, 64));
     w_max = max(w_max, __shfl_xor(w_max, 32, 64));
+    __shared__ int xs_all[4][32];
+    __shared__ uint32_t pk_lds[7 * 64];
+    int* xs = xs_all[lane >> 4];
     for (int t = 0; t < w_max; t++) {
         const bool live = t < n_warm;
-        int x[28];
-        load_unit(src, ch, first - n_warm + t, live, x);
-        uint32_t header, packed[7];
-        (void)encode_unit(cd, x, live, lane, prev1, prev2, header, packed);
+        stage_unit(xs, fetch_unit(src, ch, first - n_warm + t, live, lane), lane);
+        uint32_t header;
+        (void)encode_unit(cd, xs, live, lane, prev1, prev2, header, pk_lds);
     }
     if (!VERIFY && chunk_live && (lane & 15) == 0) {
         psxhip_adpcm_state_t s0;
@@ -310,14 +336,15 @@ __global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
     n_max = max(n_max, __shfl_xor(n_max, 16, 64));
     n_max = max(n_max, __shfl_xor(n_max, 32, 64));
     bool running = active;
+    UnitFetch nxt = fetch_unit(src, ch, first, running && 0 < n_run, lane);
     for (int t = 0; t < n_max; t++) {
         const bool live = running && t < n_run;
         if (!__any(live)) break;
         const int u = first + t;
-        int x[28];
-        load_unit(src, ch, u, live, x);
-        uint32_t header, packed[7];
-        const bool winner = encode_unit(cd, x, live, lane, prev1, prev2, header, packed);
+        stage_unit(xs, nxt, lane);
+        if (t + 1 < n_max) nxt = fetch_unit(src, ch, u + 1, running && t + 1 < n_run, lane);   // prefetch
+        uint32_t header;
+        const bool winner = encode_unit(cd, xs, live, lane, prev1, prev2, header, pk_lds);
         if (VERIFY && live) {
             // coincided with the state stored for this unit: everything after it is already consistent
             const psxhip_adpcm_state_t old = job.unit_states[st0 + u];
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(64) void adpcm_chunks_kernel(const ChunkJob job) {
                 running = false;
             }
         }
-        if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, packed);
+        if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
         if (live && (lane & 15) == 0) {
             psxhip_adpcm_state_t s1;
             s1.prev1 = prev1;
