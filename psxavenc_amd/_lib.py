@@ -44,6 +44,13 @@ def lib():
         raise ImportError(
             "psxavenc_amd: %s is missing -- build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    # PyTorch ships its own HIP runtime; whichever libamdhip64 is loaded first serves the whole process.  Import
+    # torch first (when present) so that the library and the tensors it is handed share one runtime and one view
+    # of the devices -- loading this library before torch leaves torch-allocated memory invisible to it.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
     L.psxhip_last_error.restype = C.c_char_p
