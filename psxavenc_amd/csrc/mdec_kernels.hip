@@ -152,8 +152,8 @@ struct Lds {
     uint32_t* out;          // [out_words]           frame output staging, dword j = output bytes 4j..4j+3 (pre-swizzle)
     uint16_t* mb_bits;      // [nmb][kScalesPerPass] AC bits of each macroblock at each scale of the pass
     uint32_t* mb_off;       // [nmb]                 bit offset of each macroblock in the chosen bitstream
-    uint32_t* dcw;          // [nmb*6]               per block, encode order: quantised DC (int) during pass 1, then the
-                            //                       DC code as bits << 24 | code
+    int16_t* dcv;           // [nmb*6]               per block, encode order: v2 the quantised DC; v3 the quantised DC during
+                            //                       loop (A), then the DPCM delta (codes are derived where needed)
     uint8_t* ac_len;        // [BS_LUT_SIZE]
     uint32_t* ac_code;      // [BS_LUT_SIZE]      bits << 24 | code
     uint8_t* dc_plen;       // [16]
@@ -172,7 +172,8 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int waves) {
     b += (size_t)nmb * kScalesPerPass * 2;
     b = (b + 3) & ~(size_t)3;
     b += (size_t)nmb * 4;
-    b += (size_t)nmb * 6 * 4;
+    b += (size_t)nmb * 6 * 2;
+    b = (b + 3) & ~(size_t)3;
     b += BS_LUT_SIZE;             // ac_len
     b = (b + 3) & ~(size_t)3;
     b += BS_LUT_SIZE * 4;         // ac_code
@@ -190,7 +191,7 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int wav
     L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
     L.mb_bits = (uint16_t*)(base + b);    b += (size_t)nmb * kScalesPerPass * 2;  b = (b + 3) & ~(size_t)3;
     L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
-    L.dcw = (uint32_t*)(base + b);        b += (size_t)nmb * 6 * 4;
+    L.dcv = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
     L.ac_len = (uint8_t*)(base + b);      b += BS_LUT_SIZE;                        b = (b + 3) & ~(size_t)3;
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
@@ -248,6 +249,26 @@ __device__ __forceinline__ int lut_index(int q, int run) {
 // `live` (wave-uniform) has bit s set while scale s of the pass can still fit: like the reference, which stops an
 // attempt at the first overflow (mdec.c:323-325,689-706), a scale whose running frame total already exceeds the budget
 // is not evaluated any further -- its verdict cannot change.
+// DC code of one block: v2 = the 10-bit value (mdec.c:451-453); v3 = VLC of the DPCM delta: size class = magnitude
+// bits, then a sign-dependent offset (mdec.c:285-318).  `tab` = {plen[2][8], prefix[2][8]} in LDS.
+template <int CODEC>
+__device__ __forceinline__ void dc_code(int v, int luma, const uint8_t* plen, const uint8_t* prefix, int& len, uint32_t& code) {
+    if (CODEC == 0) {
+        len = 10;
+        code = (uint32_t)v & 0x3FFu;
+        return;
+    }
+    len = luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
+    code = luma ? BS_DC_LUMA_ZERO_CODE : BS_DC_CHROMA_ZERO_CODE;
+    if (v != 0) {
+        const int ad = v < 0 ? -v : v;
+        const int mm = 31 - __builtin_clz((unsigned)ad);
+        const uint32_t j = v > 0 ? (uint32_t)(v - (1 << mm)) : (uint32_t)(v + ((2 << mm) - 1));
+        len = plen[luma * 8 + mm] + 1 + mm;
+        code = ((uint32_t)prefix[luma * 8 + mm] << (mm + 1)) | ((v > 0 ? 1u : 0u) << mm) | j;
+    }
+}
+
 template <int LIVE>
 __device__ __forceinline__ void count_block4_live(float two_abs, const float2& k0, const float2& k1, const float2& k2,
                                                   const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
@@ -474,8 +495,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //    the AC path (here, in later count passes and in emit) sees "no coefficient" at scan position 0
                     if (r8 == 0) {
                         const int dc = quant_dc(d[0]);
-                        // v2: the 10-bit code is final (mdec.c:451-453); v3: raw value for the DPCM chain below
-                        L.dcw[mbe * 6 + blk] = CODEC == 0 ? ((10u << 24) | ((uint32_t)dc & 0x3FFu)) : (uint32_t)dc;
+                        L.dcv[mbe * 6 + blk] = (int16_t)dc;     // v3: raw value for the DPCM chain below
                         d[0] = 0;
                     }
 #pragma unroll
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 const int i = base + lane;
                 const bool live = i < count;
                 const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
-                const int dc = live ? (int)L.dcw[idx] : 0;
+                const int dc = live ? (int)L.dcv[idx] : 0;
                 int thr, lo, hi;
                 if ((dc & 3) == 2) {
                     thr = dc; lo = dc + 2; hi = dc - 2;
@@ -553,19 +573,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (delta < -0x80) delta += 0x100;
                     else if (delta > 0x80) delta -= 0x100;
                 }
-                // the delta's VLC: size class = magnitude bits, then sign-dependent offset (mdec.c:285-318)
-                const int luma = wid == 2;
-                int dlen = luma ? BS_DC_LUMA_ZERO_LEN : BS_DC_CHROMA_ZERO_LEN;
-                uint32_t dcode = luma ? BS_DC_LUMA_ZERO_CODE : BS_DC_CHROMA_ZERO_CODE;
-                if (delta != 0) {
-                    const int ad = delta < 0 ? -delta : delta;
-                    const int mm = 31 - __builtin_clz((unsigned)ad);
-                    const uint32_t j = delta > 0 ? (uint32_t)(delta - (1 << mm)) : (uint32_t)(delta + ((2 << mm) - 1));
-                    dlen = L.dc_plen[luma * 8 + mm] + 1 + mm;
-                    dcode = ((uint32_t)L.dc_prefix[luma * 8 + mm] << (mm + 1)) | ((delta > 0 ? 1u : 0u) << mm) | j;
-                }
+                int dlen;
+                uint32_t dcode;
+                dc_code<CODEC>(delta, wid == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
                 if (live) {
-                    L.dcw[idx] = ((uint32_t)dlen << 24) | dcode;
+                    L.dcv[idx] = (int16_t)delta;
                     bits += dlen;
                 }
                 carry = __shfl(cur, 63, 64);
@@ -654,7 +666,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (mbe < nmb) {
                     bits = L.mb_bits[mbe * kScalesPerPass + sidx] + 12;   // six end-of-block codes
 #pragma unroll
-                    for (int b = 0; b < 6; b++) bits += (int)(L.dcw[mbe * 6 + b] >> 24);
+                    for (int b = 0; b < 6; b++) {
+                        int dlen;
+                        uint32_t dcode;
+                        dc_code<CODEC>((int)L.dcv[mbe * 6 + b], b >= 2, L.dc_plen, L.dc_prefix, dlen, dcode);
+                        bits += dlen;
+                    }
                 }
                 const int incl = wave::inclusive_scan_add(bits);
                 if (mbe < nmb) L.mb_off[mbe] = carry + (uint32_t)(incl - bits);
@@ -703,7 +720,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 int count = 0;                             // wave-uniform
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
-                    const int c = cc[b];                       // scan position 0 holds 0 in the slab (the DC term lives in dcw)
+                    const int c = cc[b];                       // scan position 0 holds 0 in the slab (the DC term lives in dcv)
                     const int q = quant_mag((float)(2 * (c < 0 ? -c : c)), inv1, bias1);     // <= 2048
                     const uint64_t m = wave::ballot(q != 0) | 1ull;
                     if (q != 0 || lane == 0)
@@ -739,9 +756,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     const uint64_t dcmask = wave::ballot(is_dc);
                     if (is_dc) {
                         const int blk = bcarry + wave::popc_below(dcmask);
-                        const uint32_t dcw = L.dcw[mbe * 6 + blk];
-                        len = (int)(dcw >> 24);
-                        code = dcw & 0xFFFFFFu;
+                        dc_code<CODEC>((int)L.dcv[mbe * 6 + blk], blk >= 2, L.dc_plen, L.dc_prefix, len, code);
                         if (blk > 0 || mbe > 0) {                   // carry the previous block's end-of-block code
                             code |= 2u << len;
                             len += 2;
