@@ -45,6 +45,8 @@ def main():
                     help="sbs = the headline MDEC metric (default); xacd = config 5, ADPCM-only XA sectors/s (secondary)")
     ap.add_argument("--audio-seconds", type=float, default=600.0, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
     ap.add_argument("--xa-channels", type=int, default=8)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing: several ranks may share a GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo)")
     args = ap.parse_args()
     if args.workload == "xacd":
         return bench_xacd(args)
@@ -59,6 +61,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -66,7 +70,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from psxavenc_amd import synth
     from psxavenc_amd.mdec import MdecEncoder
@@ -91,7 +98,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -105,7 +115,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
@@ -195,13 +205,19 @@ def bench_xacd(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # where the tiny exchange tensors live
     from psxavenc_amd import adpcm, synth
     from psxavenc_amd.parallel import run_time_sharded, shard_range
 
@@ -231,7 +247,7 @@ def bench_xacd(args):
     def step():
         sess = adpcm.AdpcmSession(pcm.reshape(-1), chains, base, 4, 4, d_units=d_units, lead_units=lead, chunk_units=chunk_units,
                                   warmup_units=warmup_units)
-        run_time_sharded(sess, rank, world, dist, init, device=dev)
+        run_time_sharded(sess, rank, world, dist, init, device=xdev)
         outs = [adpcm.xa_assemble_device(d_units[c * sec_cnt * 144:], sec_cnt, settings, first_lba=sec0) for c in range(n_ch)]
         passes = sess.passes
         sess.close()
@@ -243,7 +259,10 @@ def bench_xacd(args):
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -253,7 +272,7 @@ def bench_xacd(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
