@@ -1,0 +1,35 @@
+"""Soak: many seeded frames / budgets / codecs through the batched HIP path, every byte against the oracle."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from psxavenc_amd.mdec import MdecEncoder
+rng = np.random.default_rng(777)
+total = bad = 0
+t0 = time.time()
+for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
+    codec = rnd % 3
+    w, h = [(320, 240), (320, 240), (160, 112), (640, 480)][rnd % 4]
+    n = 500 if w <= 320 else 60
+    amp = int(rng.integers(0, 40))
+    frames = O.synth_frames(w, h, n, seed=int(rng.integers(1, 1 << 30)), amp=amp, first=int(rng.integers(0, 100000)))
+    lo = 8 + 2 * (((w // 16) * (h // 16) * 6 * 12 + 10 + 15) // 16)
+    budgets = rng.integers(lo + 200, lo + 200 + int(rng.integers(500, 40000)), n).astype(np.int32)
+    want, want_res, rc = O.mdec_encode(codec, w, h, frames, budgets, stride=int(budgets.max()))
+    if rc != 0:
+        # some frame fits no scale: encode one by one
+        keep = []
+        for k in range(n):
+            _, _, r1 = O.mdec_encode(codec, w, h, frames[k:k + 1], int(budgets[k]))
+            if r1 == 0: keep.append(k)
+        frames, budgets = frames[keep], budgets[keep]
+        want, want_res, rc = O.mdec_encode(codec, w, h, frames, budgets, stride=int(budgets.max()))
+        n = len(keep)
+    enc = MdecEncoder(codec, w, h, max_frame_size=int(budgets.max()))
+    out, res = enc.encode_frames_host(frames, budgets)
+    ok = np.array_equal(out, want) and np.array_equal(res, want_res)
+    total += n; bad += 0 if ok else 1
+    print("round %2d codec %d %dx%d amp %2d frames %3d scales %2d..%2d %s" % (rnd, codec, w, h, amp, n, res[:, 0].min(), res[:, 0].max(), "ok" if ok else "MISMATCH"), flush=True)
+    enc.close()
+print("soak: %d frames, %d mismatching rounds, %.0f s" % (total, bad, time.time() - t0))
