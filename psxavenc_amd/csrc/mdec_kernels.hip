@@ -402,7 +402,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
 
     for (int f = (int)blockIdx.x; f < job.n_frames; f += (int)gridDim.x) {
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
-        const int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
+        int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
+        // per-frame budgets live in device memory the host cannot vet: a budget outside [8, the context's maximum]
+        // is treated as "nothing fits" (result quant_scale 64, no bytes written) instead of overrunning the staging
+        const bool bad_budget = max_size < 8 || max_size > (job.out_words - 2) * 4;
+        if (bad_budget) max_size = 8;
         const int max_words = (max_size + 3) >> 2;
         // a scale is hopeless once its AC bits alone exceed what the budget leaves after the cheapest possible
         // DC codes (v2: 10 bits, v3: >= 2 bits), the end-of-block codes and the end-of-frame code:
@@ -642,9 +646,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const int scale = L.scalars[1];
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
-        if (scale == 0) {
+        if (scale == 0 || bad_budget) {
             // nothing fits (the reference asserts, mdec.c:723): zero output, flag the result
-            for (int i = tid; i < max_size; i += kThreads) outp[i] = 0;
+            if (!bad_budget)
+                for (int i = tid; i < max_size; i += kThreads) outp[i] = 0;
             if (tid == 0) {
                 psxhip_mdec_result_t r;
                 r.quant_scale = 64; r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;

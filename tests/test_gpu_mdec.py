@@ -276,3 +276,26 @@ def test_randomised_geometry_content_budgets_vs_oracle():
                 n_nofit += 1
         enc.close()
     assert n_cases > 80 and n_nofit > 0
+
+
+def test_out_of_range_device_budgets_are_contained(torch_cuda):
+    """per-frame budgets come from device memory: values outside [8, context maximum] must flag the frame
+    (quant_scale 64) without touching its output row or anyone else's"""
+    torch = torch_cuda
+    w, h, n, cap = 48, 32, 6, 4096
+    fr = O.synth_frames(w, h, n, seed=2, amp=4)
+    enc = encoder(1, w, h, cap)
+    d = torch.from_numpy(fr).to("cuda:0")
+    budgets = torch.tensor([4096, 1 << 20, 4096, 0, -5, 2048], dtype=torch.int32, device="cuda:0")
+    d_out = torch.full((n, cap), 0xAB, dtype=torch.uint8, device="cuda:0")
+    d_out, d_res = enc.encode_frames_device(d, budgets, d_out=d_out)
+    torch.cuda.synchronize()
+    out, res = d_out.cpu().numpy(), d_res.cpu().numpy()
+    for k, b in enumerate([4096, None, 4096, None, None, 2048]):
+        if b is None:
+            assert res[k, 0] == 64 and (out[k] == 0xAB).all()
+        else:
+            want, want_res, rc = O.mdec_encode(1, w, h, fr[k:k + 1], b)
+            assert rc == 0 and np.array_equal(out[k, :b], want[0]) and np.array_equal(res[k], want_res[0])
+            assert (out[k, b:] == 0xAB).all()
+    enc.close()
