@@ -48,8 +48,10 @@ typedef struct {
 typedef struct psxhip_mdec_ctx psxhip_mdec_ctx_t;
 
 /* codec: 0 = BS v2, 1 = v3, 2 = v3dc (bs_codec_t, psxavenc/args.h:61-65).
- * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 x 1024.
- * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging). */
+ * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 each.
+ * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging).
+ * A frame's working set (budget + ~19 bytes per macroblock + ~45 KiB) must fit the CU's 160 KiB LDS, else
+ * PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to ~64 KiB budgets. */
 int psxhip_mdec_create(psxhip_mdec_ctx_t **ctx, int device, int codec, int width, int height,
                        int max_frame_size);
 void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
