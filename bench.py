@@ -26,46 +26,40 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (config 'sbs v2': 1000)")
-    ap.add_argument("--width", type=int, default=320)
-    ap.add_argument("--height", type=int, default=240)
-    ap.add_argument("--budget", type=int, default=8192, help="frame_max_size = sbs alignment (args.c:184)")
-    ap.add_argument("--codec", type=int, default=0, help="0 = BS v2, 1 = v3, 2 = v3dc")
-    ap.add_argument("--amp", type=int, default=4, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
-    ap.add_argument("--workload", choices=["sbs", "xacd"], default="sbs",
-                    help="sbs = the headline MDEC metric (default); xacd = config 5, ADPCM-only XA sectors/s (secondary)")
-    ap.add_argument("--audio-seconds", type=float, default=600.0, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
-    ap.add_argument("--xa-channels", type=int, default=8)
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing: several ranks may share a GPU)")
-    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo)")
-    args = ap.parse_args()
-    if args.workload == "xacd":
-        return bench_xacd(args)
-
-    import numpy as np
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one process per GPU)."""
+    import socket
+    import subprocess
     import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not args.share_gpu:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (use --share-gpu --dist-backend gloo to test on one)" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
+
+def _init_dist(args):
+    """Returns (rank, world, local_rank, dev, dist-or-None, xdev)."""
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if args.share_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: GPU %d not visible (%d present)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -74,12 +68,135 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # where the tiny exchange tensors live
+    return rank, world, local_rank, dev, dist, xdev
 
-    from psxavenc_amd import synth
+
+def _barrier(args, dist, local_rank):
+    import torch
+    torch.cuda.synchronize()
+    if dist is not None:
+        if args.dist_backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _gather_ranks(dist, xdev, values):
+    """all-gather a few per-rank numbers (float64); returns a list of lists in rank order."""
+    import torch
+    t = torch.tensor(values, dtype=torch.float64, device=xdev)
+    if dist is None:
+        return [t.tolist()]
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [o.tolist() for o in outs]
+
+
+def _stats(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    med = xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+    return {"median": round(med, 5), "min": round(xs[0], 5), "max": round(xs[-1], 5), "mean": round(sum(xs) / n, 5), "n": n}
+
+
+def _profile_traffic(key):
+    """HBM-side traffic per launch of the dominant kernel, from the committed rocprofv3 PMC summary whose key
+    (workload + library version) matches this run -- PMC counters cannot be read from inside the process, they come
+    from separate `rocprofv3 --pmc` passes of this same command (tools/gpu_rocprof_mdec.sh).  None when no summary matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as fh:
+            idx = json.load(fh)
+        e = idx.get(key)
+        if e:
+            return e["traffic_bytes_per_launch"], e["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def _cpu_baseline_mdec(O, codec, w, h, budget, frames, seconds):
+    """oracle/mdec_oracle.c on the host: one core (the reference is single-threaded), then every core with one
+    encoder per thread over disjoint frame ranges (legal: no globals).  ctypes releases the GIL."""
+    import threading
+    n = frames.shape[0]
+    chunk = 125
+
+    def work(lo, stop_at, counter):
+        done = 0
+        while time.perf_counter() < stop_at:
+            a = (lo + done) % n
+            b = min(n, a + chunk)
+            O.mdec_encode(codec, w, h, frames[a:b], budget)
+            done += b - a
+        counter.append(done)
+
+    t0 = time.perf_counter()
+    c1 = []
+    work(0, t0 + seconds * 0.6, c1)
+    t1 = time.perf_counter() - t0
+    one = c1[0] / t1
+    cores = os.cpu_count() or 1
+    nthr = max(1, min(cores, 256))
+    cs, ths = [], []
+    t0 = time.perf_counter()
+    stop = t0 + seconds * 0.4
+    for i in range(nthr):
+        th = threading.Thread(target=work, args=((i * chunk) % n, stop, cs))
+        th.start()
+        ths.append(th)
+    for th in ths:
+        th.join()
+    tn = time.perf_counter() - t0
+    return {"value": round(one, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload in %.1f s (oracle/mdec_oracle.c, gcc -O3; the FFmpeg-linked reference cannot be built here)" % (c1[0], t1),
+            "all_cores": {"value": round(sum(cs) / tn, 2), "unit": "frames/s", "cores": nthr, "nproc": cores,
+                          "sample": "%d frames in %.1f s, one encoder per thread" % (sum(cs), tn)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--launches-per-step", type=int, default=16,
+                    help="a step = this many back-to-back launches of the configured batch (so that 20 steps time >= 300 launches)")
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per launch (config 'sbs v2': 1000)")
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--budget", type=int, default=8192, help="frame_max_size = sbs alignment (args.c:184)")
+    ap.add_argument("--codec", type=int, default=0, help="0 = BS v2, 1 = v3, 2 = v3dc")
+    ap.add_argument("--amp", type=int, default=4, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
+    ap.add_argument("--workload", choices=["sbs", "xacd", "strcd"], default="sbs",
+                    help="sbs = the headline MDEC metric (default); xacd = config 5, ADPCM-only XA sectors/s; "
+                         "strcd = config 3, MDEC + XA ADPCM muxed into 2352-byte sectors")
+    ap.add_argument("--audio-seconds", type=float, default=600.0, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
+    ap.add_argument("--xa-channels", type=int, default=8)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing: several ranks may share a GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _spawn_ranks(args)
+    if args.workload == "xacd":
+        return bench_xacd(args)
+    if args.workload == "strcd":
+        return bench_strcd(args)
+
+    import numpy as np
+    import torch
+
+    rank, world, local_rank, dev, dist, xdev = _init_dist(args)
+
+    from psxavenc_amd import _lib, synth
     from psxavenc_amd.mdec import MdecEncoder
     from psxavenc_amd.parallel import shard_range
 
-    w, h, budget, n = args.width, args.height, args.budget, args.frames
+    w, h, budget, n, lps = args.width, args.height, args.budget, args.frames, max(1, args.launches_per_step)
     first, count = shard_range(n * world, rank, world)     # contiguous frame ranges per rank (SURVEY 8(e))
     assert count == n
     enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
@@ -89,40 +206,32 @@ def main():
     d_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    def step():
+    def launch():
         enc.encode_frames_device(d_frames, budget, d_out=d_out, d_results=d_res)
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(args.warmup * lps):
+        launch()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            if args.dist_backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-        torch.cuda.synchronize()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
+    # one HIP event pair per launch, on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * lps)]
+    _barrier(args, dist, local_rank)
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(args.steps * lps):
         ev[k][0].record()
-        step()
+        launch()
         ev[k][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    _barrier(args, dist, local_rank)
+    elapsed_local = time.perf_counter() - t0
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps)])
+    elapsed = max(r[0] for r in per_rank)                   # max over ranks
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kstat = _stats(kernel_ms)
 
     # ---- post-timing: every rank checks its results are sane; rank 0 diffs a sample against the oracle
     res = d_res.cpu().numpy()
     ok_local = bool(((res[:, 0] >= 1) & (res[:, 0] <= 63)).all())
+    scale_sum = _gather_ranks(dist, xdev, [float(res[:, 0].sum()), float(ok_local)])
     parity = None
     cpu_baseline = None
     if rank == 0:
@@ -134,33 +243,16 @@ def main():
         got = d_out[torch.from_numpy(idx).to(dev)].cpu().numpy()[:, :budget]
         parity = {"frames_checked": int(k), "bit_exact": bool(rc == 0 and np.array_equal(got, want) and np.array_equal(res[idx], want_res))}
         if world == 1 and not args.no_cpu_baseline:
-            fr_all = d_frames.cpu().numpy()
-            done, t_cpu = 0, 0.0
-            chunk = 250
-            while t_cpu < args.cpu_seconds:
-                lo = done % n
-                c0 = time.perf_counter()
-                O.mdec_encode(args.codec, w, h, fr_all[lo:lo + chunk], budget)
-                t_cpu += time.perf_counter() - c0
-                done += min(chunk, n - lo)
-            cpu_baseline = {"value": round(done / t_cpu, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                            "sample": "%d frames of the same workload (oracle/mdec_oracle.c, gcc -O3, %d host cores present)" % (done, os.cpu_count() or 0)}
+            cpu_baseline = _cpu_baseline_mdec(O, args.codec, w, h, budget, d_frames.cpu().numpy(), args.cpu_seconds)
 
-    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 PMC passes of this same command
-    # (PMC counters cannot be read from inside the process); the committed summary is quoted when the workload matches
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc.json")) as fh:
-            pmc = json.load(fh)
-        if (args.codec, w, h, budget, n, args.amp) == (0, 320, 240, 8192, 1000, 4):
-            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_v4_pmc.json"
-    except Exception:
-        pass
+    version = _lib.lib().psxhip_version().decode()
+    wl_key = "sbs codec=%d %dx%d budget=%d frames=%d amp=%d | %s" % (args.codec, w, h, budget, n, args.amp, version)
+    traffic, traffic_src = _profile_traffic(wl_key)
 
-    total_frames = n * world * args.steps
+    total_frames = n * world * args.steps * lps
     value = total_frames / elapsed
     alg_bytes = (w * h * 3 // 2 + budget) * n            # per launch: NV21 read + frame_max_size written, per frame
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
     scales, counts = np.unique(res[:, 0], return_counts=True)
 
     if rank == 0:
@@ -177,18 +269,22 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "sbs v2: %d synthetic %dx%d NV21 frames per GPU per step, frame_max_size %d, codec %s, noise +-%d"
-                                   % (n, w, h, budget, ["v2", "v3", "v3dc"][args.codec], args.amp),
-                       "frames_per_gpu": n, "width": w, "height": h, "frame_max_size": budget,
-                       "parallelism": "frames sharded x%d, no data-path collective" % world,
-                       "quant_scale_hist": {str(int(s)): int(c) for s, c in zip(scales, counts)}},
+            "config": {"workload": "sbs %s: %d synthetic %dx%d NV21 frames per GPU per launch, %d launches per step, frame_max_size %d, "
+                                   "noise +-%d; inputs resident in HBM, outputs stay in HBM (no D2H inside the timed region)"
+                                   % (["v2", "v3", "v3dc"][args.codec], n, w, h, lps, budget, args.amp),
+                       "frames_per_gpu_per_launch": n, "launches_per_step": lps, "width": w, "height": h, "frame_max_size": budget,
+                       "parallelism": "frames sharded x%d (contiguous ranges per rank), no data-path collective" % world,
+                       "quant_scale_hist": {str(int(s)): int(c) for s, c in zip(scales, counts)},
+                       "library": version},
+            "per_rank": [{"rank": i, "frames_per_sec": round(r[1] / r[0], 1), "elapsed_s": round(r[0], 4),
+                          "quant_scale_sum": int(q[0]), "results_sane": bool(q[1])} for i, (r, q) in enumerate(zip(per_rank, scale_sum))],
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": traffic_src, "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
+                         "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu_baseline,
             "parity": parity,
-            "results_sane": ok_local,
+            "results_sane": all(bool(q[1]) for q in scale_sum),
         }
         print(json.dumps(line), flush=True)
     enc.close()
@@ -202,22 +298,7 @@ def bench_xacd(args):
     all-gather (psxavenc_amd/parallel.py).  A step = encode the whole audio from scratch + assemble this rank's sectors."""
     import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # where the tiny exchange tensors live
+    rank, world, local_rank, dev, dist, xdev = _init_dist(args)
     from psxavenc_amd import adpcm, synth
     from psxavenc_amd.parallel import run_time_sharded, shard_range
 
@@ -257,13 +338,7 @@ def bench_xacd(args):
         step()
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            if args.dist_backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-        torch.cuda.synchronize()
+        _barrier(args, dist, local_rank)
 
     barrier()
     t0 = time.perf_counter()
@@ -311,6 +386,10 @@ def bench_xacd(args):
             "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_strcd(args):
+    raise SystemExit("--workload strcd: see psxavenc_amd/strmux.py (not wired into bench.py yet)")
 
 
 if __name__ == "__main__":

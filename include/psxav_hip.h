@@ -60,7 +60,11 @@ void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
  * d_out + i*out_stride.  Exactly frame_max_size bytes are written per frame: header, bitstream,
  * zero fill -- what psxavenc/mdec.c:676,739-754 leave in frame_output.  d_frame_max_sizes may be
  * NULL, then every frame uses uniform_max_size.  d_frames, d_out, frame_stride and out_stride
- * must be 4-byte aligned.  Asynchronous on `stream`; results land in d_results[i]. */
+ * must be 4-byte aligned.  Asynchronous on `stream`; results land in d_results[i].
+ * Launches on ONE context must be stream-ordered (same stream, or ordered by events): the context owns the
+ * frame hand-out counters the kernel uses.  Use one context per concurrent stream.
+ * Per-frame budgets (device memory, not vetted by the host) outside [8, min(the context's max_frame_size,
+ * out_stride)] make that frame's result quant_scale 64 and write nothing. */
 int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t *ctx, const uint8_t *d_frames, size_t frame_stride,
                                      int n_frames, const int32_t *d_frame_max_sizes, int uniform_max_size,
                                      uint8_t *d_out, size_t out_stride, psxhip_mdec_result_t *d_results,
@@ -75,11 +79,32 @@ int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t *ctx, const uint8_t *frames
 /* Name and grid of the kernel the last encode call launched (for bench.py's roofline block). */
 const char *psxhip_mdec_kernel_name(void);
 
-/* Diagnostics: when the context was created with PSXHIP_MDEC_TIMING=1 in the environment, the kernel
- * accumulates shader-clock cycles per phase (summed over workgroups): 0 reset, 1 DCT + first count pass,
- * 2 DC chain, 3 rate control (incl. further count passes), 4 offset scan, 5 emit, 6 finalise + write-out.
- * Zeros otherwise. */
-int psxhip_mdec_read_timing(psxhip_mdec_ctx_t *ctx, unsigned long long *out8, int reset);
+/* What a geometry costs, before creating a context for it.  A frame's working set lives in the CU's
+ * 160 KiB LDS: about 2 * max_frame_size + 28 bytes per macroblock + ~37 KiB (two workgroups per CU when twice
+ * that fits, else one).  fits == 0 means psxhip_mdec_create would return PSXHIP_EINVAL; max_frame_size_limit
+ * is the largest budget this frame size supports (e.g. 320x240: ~58 KiB, 640x480: ~49 KiB). */
+typedef struct {
+	int32_t fits;
+	int32_t groups_per_cu;          /* frames in flight per compute unit (2 or 1) */
+	int32_t wavefronts_per_group;
+	int32_t frames_in_flight;       /* persistent grid size = compute units * groups_per_cu */
+	int32_t max_frame_size_limit;
+	int32_t reserved;
+	int64_t lds_bytes_per_group;
+	int64_t lds_bytes_per_cu;
+} psxhip_mdec_geometry_t;
+int psxhip_mdec_query_geometry(int device, int codec, int width, int height, int max_frame_size,
+                               psxhip_mdec_geometry_t *out);
+
+/* Diagnostics: when the context was created with PSXHIP_MDEC_STATS=1 in the environment, the kernel counts
+ * [0] frames encoded, [1] passes over frames (1 per frame when the pilot's prediction held), [2..7] histogram of
+ * passes per frame (0, 1, 2, 3, 4, >= 5).  Copies min(n, PSXHIP_MDEC_STATS_TOTAL) entries; zeros otherwise. */
+#define PSXHIP_MDEC_STATS 8
+/* after those, 4 entries per workgroup (the first PSXHIP_MDEC_TRACE_GROUPS groups of the last launch): start and end
+ * time (100 MHz wall clock), frames encoded, reserved */
+#define PSXHIP_MDEC_TRACE_GROUPS 1024
+#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS + 4 * PSXHIP_MDEC_TRACE_GROUPS)
+int psxhip_mdec_read_stats(psxhip_mdec_ctx_t *ctx, unsigned long long *out, int n, int reset);
 
 /* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */
 

@@ -5,25 +5,33 @@
 // zig-zag/RLE -> BS v2/v3 VLC -> bit-pack, inside the "first quant scale that fits" loop.
 //
 // Mapping (see DESIGN.md for the reasoning):
-//   * one workgroup (16 wavefronts) owns one frame at a time and loops over frames (persistent grid);
+//   * one workgroup owns one frame at a time (persistent grid, frames handed out by an atomic ticket);
 //   * one wavefront owns one macroblock at a time: 48 lanes run the row / column DCT butterflies of
-//     the six 8x8 blocks (8x8 transposes staged in LDS), then lane k owns zig-zag position k;
-//   * quantisation is an exact integer rounding division done with one fp32 multiply (proof in
-//     quant_level()); run lengths come from a 64-bit ballot + count-leading-zeros; code lengths and
-//     codes from a (run, |level|) LUT held in LDS; bit offsets from DPP prefix sums;
-//   * the rate-control loop evaluates kScalesPerPass scales per pass over the frame's coefficients
-//     (kept as int16 in an L2-resident scratch slab) and takes the FIRST scale that fits, exactly
-//     like the reference's ascending loop (bits(s) is not provably monotone, so no bisection);
-//   * the chosen scale's bitstream is assembled in LDS with ds_or and leaves the CU as coalesced
-//     dword stores, header and zero tail included (the reference's memset, mdec.c:676).
+//     the six 8x8 blocks on packed int16 pairs (v_pk_add_i16 + v_dot2_i32_i16; 8x8 transposes staged in
+//     LDS), then lane k owns zig-zag position k of every block;
+//   * quantisation is an exact integer rounding division done with one fp32 fma (proof at quant_mag());
+//     run lengths come from a 64-bit ballot + count-leading-zeros; code lengths and codes from
+//     (run, |level|) LUTs held in LDS; bit offsets from DPP prefix sums;
+//   * rate control does NOT evaluate every scale.  A pilot (one macroblock per wavefront, strided over
+//     the frame) predicts the answer p; one fused pass over the frame then counts the bits at p-1 and
+//     builds the bitstream at p.  The count also yields a proven lower bound for ALL finer scales
+//     (mdec_search.h), so "p-1 and everything below it fail, p fits" is established exactly like the
+//     reference's ascending loop would -- in one pass.  Mispredictions cost further passes (the DCT is
+//     recomputed from the frame, which is L2 / Infinity-Cache resident), never exactness;
+//   * macroblock bitstreams are built independently in an LDS staging area (a macroblock's position in the
+//     frame's stream depends on all macroblocks before it), then an exclusive scan in encode order and a
+//     funnel-shift merge place them; the frame leaves the CU as coalesced dword stores, header and zero
+//     tail included (the reference's memset, mdec.c:676).
+// There is no per-frame scratch in global memory: a frame's coefficients never leave the CU.
 //
-// MFMA is deliberately not used: the DCT is the bit-exact integer "islow" butterfly (see
-// fdct8()), not a dense contraction, and everything after it is integer / bit manipulation.
+// MFMA is deliberately not used: the DCT is the bit-exact integer "islow" butterfly (see fdct8_pk()),
+// not a dense contraction, and everything after it is integer / bit manipulation.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "bs_vlc_lut.h"
+#include "mdec_search.h"
 #include "psxhip_internal.h"
 #include "wave_ops.h"
 
@@ -33,11 +41,11 @@ namespace {
 // otherwise 16 wavefronts at 4 per SIMD (one frame per CU; 128 VGPRs) -- large frames / large budgets.
 constexpr int kWavesSmall = 12, kOccSmall = 6;
 constexpr int kWavesLarge = 16, kOccLarge = 4;
-constexpr int kScalesPerPass = 4;
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
 constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
+constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 
-__constant__ uint8_t c_ac_len[BS_LUT_SIZE];
+__constant__ uint16_t c_ac_len16[BS_LUT_SIZE];
 __constant__ uint32_t c_ac_code[BS_LUT_SIZE];
 __constant__ uint8_t c_zagzig[64];
 __constant__ uint8_t c_quant_zz[64];
@@ -54,90 +62,111 @@ struct FrameJob {
     uint8_t* out;
     size_t out_stride;
     psxhip_mdec_result_t* results;
-    int16_t* coef_slab;      // [gridDim.x][nmb][6][64], zig-zag order
     int out_words;           // LDS dwords reserved for one frame's output
-    unsigned long long* timing;   // optional [8] phase cycle counters (diagnostics), NULL in normal runs
+    int stg_words;           // LDS dwords of the macroblock staging area
+    unsigned int* ticket;    // [2]: next frame to hand out, workgroups finished (self-resetting)
+    unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
+    unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
+
+// scalars[] slots (LDS, per workgroup)
+enum {
+    S_DC_BITS = 0,      // v3: sum of the DC code lengths
+    S_STG_NEXT,         // staging bump allocator (dwords)
+    S_OVERFLOW,         // staging ran out during this pass
+    S_CNT_F,            // count pass: sum of AC code lengths
+    S_CNT_D,            // count pass: sum of refinement deficits
+    S_EMIT_BITS,        // emit pass: sum of macroblock stream lengths
+    S_EMIT_D,           // emit pass: sum of refinement deficits
+    S_NNZ,              // emit pass: non-zero AC coefficients
+    S_PASS_COUNT,       // next pass: count scale
+    S_PASS_EMIT,        // next pass: emit scale
+    S_DONE,             // search finished
+    S_RESULT,           // chosen scale (64 = nothing fits)
+    S_TOTAL_BITS,       // bits of the staged stream incl. the end-of-frame code
+    S_FRAME,            // ticket
+    S_PILOT_N,          // scales in this pilot round (0 = pilot finished)
+    S_PILOT_GUESS,
+    S_PILOT_LO,
+    S_PILOT_HI,
+    S_SEARCH,           // MdecSearch (14 ints)
+    S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
+    S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
+    S_COUNT = S_PILOT_BITS0 + kPilotMax
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+constexpr uint32_t pk(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 
 // ---------------------------------------------------------------------------------------------
 // 8-point forward DCT, IJG "jfdctint" (Loeffler-Ligtenberg-Moschytz) for 8-bit samples as
 // libavcodec specialises it (ff_jpeg_fdct_islow_8, the routine psxavenc's AVDCT call resolves to in
 // the release configuration; mdec.c:640, .github/scripts/build.sh:36-56).  13-bit constants, 4
 // fractional bits kept after the row pass.  COLUMN selects the output scaling of the second pass.
+//
+// Restated as integer linear forms (exact in the ring Z / 2^32, no intermediate rounding is moved):
+// with the folded sums / differences  s_ij = d_i + d_j,  o0..o3 = d3-d4, d2-d5, d1-d6, d0-d7,
+//     out0 = s07 + s16 + s25 + s34                out4 = s07 - s16 - s25 + s34
+//     out2 = (s07 - s34) (K541 + K765) + (s16 - s25) K541
+//     out6 = (s07 - s34) K541 + (s16 - s25) (K541 - K1847)
+//     out7, 5, 3, 1 = the jfdctint odd part multiplied out: four coefficients per output
+// every output is two v_dot2_i32_i16 on packed (int16, int16) operands, the rounding constant riding in the
+// accumulator.  Operand ranges: row pass |s| <= 510, |o| <= 255; column pass |s|, |o| <= 32768 - 128 (row outputs
+// are bounded by 16 * 8 * 128), so the packed int16 adds cannot wrap.  Inputs: P0 = (d0, d1), P1 = (d2, d3),
+// R0 = (d7, d6), R1 = (d5, d4).  The row pass takes RAW pixels 0..255: the level shift by -128
+// (mdec.c:627-632) only moves out0, by -8 * 128.
+// tests/test_mdec_oracle.py::test_dct_linear_forms checks these forms against the oracle's butterfly.
 // ---------------------------------------------------------------------------------------------
 template <bool COLUMN>
-__device__ __forceinline__ void fdct8(int (&d)[8]) {
+__device__ __forceinline__ void fdct8_pk(uint32_t P0, uint32_t P1, uint32_t R0, uint32_t R1, int (&d)[8]) {
     constexpr int K_0_298 = 2446, K_0_390 = 3196, K_0_541 = 4433, K_0_765 = 6270, K_0_899 = 7373,
                   K_1_175 = 9633, K_1_501 = 12299, K_1_847 = 15137, K_1_961 = 16069, K_2_053 = 16819,
                   K_2_562 = 20995, K_3_072 = 25172;
     constexpr int SH = COLUMN ? 13 + 4 : 13 - 4;
     constexpr int RND = 1 << (SH - 1);
+    // even part
+    constexpr int A = K_0_541 + K_0_765, B = K_0_541, C = K_0_541 - K_1_847;
+    // odd part: coefficient of o_j in out_i
+    constexpr int C7_0 = K_0_298 - K_0_899 - K_1_961 + K_1_175, C7_1 = K_1_175, C7_2 = K_1_175 - K_1_961, C7_3 = K_1_175 - K_0_899;
+    constexpr int C5_0 = K_1_175, C5_1 = K_2_053 - K_2_562 - K_0_390 + K_1_175, C5_2 = K_1_175 - K_2_562, C5_3 = K_1_175 - K_0_390;
+    constexpr int C3_0 = K_1_175 - K_1_961, C3_1 = K_1_175 - K_2_562, C3_2 = K_3_072 - K_2_562 - K_1_961 + K_1_175, C3_3 = K_1_175;
+    constexpr int C1_0 = K_1_175 - K_0_899, C1_1 = K_1_175 - K_0_390, C1_2 = K_1_175, C1_3 = K_1_501 - K_0_899 - K_0_390 + K_1_175;
+    static_assert(A < 32768 && C > -32768 && C7_0 > -32768 && C1_3 < 32768 && C5_2 > -32768 && C3_1 > -32768, "int16 operands");
 
-    const int s07 = d[0] + d[7], s16 = d[1] + d[6], s25 = d[2] + d[5], s34 = d[3] + d[4];
-    int o0 = d[3] - d[4], o1 = d[2] - d[5], o2 = d[1] - d[6], o3 = d[0] - d[7];
-    const int e0 = s07 + s34, e3 = s07 - s34, e1 = s16 + s25, e2 = s16 - s25;
+    const uint32_t S0 = pk_add(P0, R0);   // (s07, s16)
+    const uint32_t S1 = pk_add(P1, R1);   // (s25, s34)
+    const uint32_t D0 = pk_sub(P0, R0);   // (o3, o2)
+    const uint32_t D1 = pk_sub(P1, R1);   // (o1, o0)
 
     if (COLUMN) {
-        d[0] = (e0 + e1 + 8) >> 4;
-        d[4] = (e0 - e1 + 8) >> 4;
+        d[0] = dot2(S0, pk(1, 1), dot2(S1, pk(1, 1), 8)) >> 4;
+        d[4] = dot2(S0, pk(1, -1), dot2(S1, pk(-1, 1), 8)) >> 4;
     } else {
-        d[0] = (e0 + e1) * 16;
-        d[4] = (e0 - e1) * 16;
+        d[0] = dot2(S0, pk(1, 1), dot2(S1, pk(1, 1), -8 * 128)) * 16;
+        d[4] = dot2(S0, pk(1, -1), dot2(S1, pk(-1, 1), 0)) * 16;
     }
-    const int r = (e2 + e3) * K_0_541;
-    d[2] = (r + e3 * K_0_765 + RND) >> SH;
-    d[6] = (r - e2 * K_1_847 + RND) >> SH;
-
-    int z1 = o0 + o3, z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
-    const int z5 = (z3 + z4) * K_1_175;
-    o0 *= K_0_298;
-    o1 *= K_2_053;
-    o2 *= K_3_072;
-    o3 *= K_1_501;
-    z1 *= -K_0_899;
-    z2 *= -K_2_562;
-    z3 = z3 * -K_1_961 + z5;
-    z4 = z4 * -K_0_390 + z5;
-    d[7] = (o0 + z1 + z3 + RND) >> SH;
-    d[5] = (o1 + z2 + z4 + RND) >> SH;
-    d[3] = (o2 + z2 + z3 + RND) >> SH;
-    d[1] = (o3 + z1 + z4 + RND) >> SH;
+    d[2] = dot2(S0, pk(A, B), dot2(S1, pk(-B, -A), RND)) >> SH;
+    d[6] = dot2(S0, pk(B, C), dot2(S1, pk(-C, -B), RND)) >> SH;
+    d[7] = dot2(D0, pk(C7_3, C7_2), dot2(D1, pk(C7_1, C7_0), RND)) >> SH;
+    d[5] = dot2(D0, pk(C5_3, C5_2), dot2(D1, pk(C5_1, C5_0), RND)) >> SH;
+    d[3] = dot2(D0, pk(C3_3, C3_2), dot2(D1, pk(C3_1, C3_0), RND)) >> SH;
+    d[1] = dot2(D0, pk(C1_3, C1_2), dot2(D1, pk(C1_1, C1_0), RND)) >> SH;
 }
-
-// diagnostics: thread 0 of a workgroup accumulates s_memtime deltas per phase
-struct PhaseClock {
-    unsigned long long* dst;
-    unsigned long long last;
-    __device__ __forceinline__ void start(unsigned long long* d) {
-        dst = d;
-        if (dst && threadIdx.x == 0) last = __builtin_readcyclecounter();
-    }
-    __device__ __forceinline__ void mark(int phase) {
-        if (dst && threadIdx.x == 0) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            atomicAdd(&dst[phase], now - last);
-            last = now;
-        }
-    }
-};
 
 // wave-level ordering point for LDS traffic between lanes of the same wavefront
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Quantiser.  The reference computes (int)round((double)n / (double)d)  (mdec.c:438): round half
-// away from zero, i.e.  sgn(n) * floor((2|n| + d) / (2d)).   With N = 2|n| + d and D = 2d,
-// floor(N / D) == floor((N + 0.5) / D), and (N + 0.5) / D is at least 0.5 / D away from every
-// integer.  N < 2^17, so N + 0.5 is exact in fp32; one rcp (<= 1 ulp) and one multiply put the
-// product within (N + 0.5) * 1.5 * 2^-23 / D of the true quotient, which is < 0.5 / D for
-// N < 2.7e6.  Truncation therefore gives the exact floor.  `two_abs` = 2|n|, `d` = quant * scale,
-// `inv2d` = 1 / (2d).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int quant_level(int two_abs, int d, float inv2d) {
-    return (int)(((float)(two_abs + d) + 0.5f) * inv2d);
 }
 
 // DC: divisor is always 16 (mdec.c:671), clamp to [-512, 510] (mdec.c:260-267).
@@ -149,56 +178,55 @@ __device__ __forceinline__ int quant_dc(int c0) {
 }
 
 struct Lds {
-    uint32_t* out;          // [out_words]           frame output staging, dword j = output bytes 4j..4j+3 (pre-swizzle)
-    uint16_t* mb_bits;      // [nmb][kScalesPerPass] AC bits of each macroblock at each scale of the pass
-    uint32_t* mb_off;       // [nmb]                 bit offset of each macroblock in the chosen bitstream
-    int16_t* dcv;           // [nmb*6]               per block, encode order: v2 the quantised DC; v3 the quantised DC during
-                            //                       loop (A), then the DPCM delta (codes are derived where needed)
-    uint8_t* ac_len;        // [BS_LUT_SIZE]
-    uint32_t* ac_code;      // [BS_LUT_SIZE]      bits << 24 | code
+    uint32_t* out;          // [out_words]   frame output staging, dword j = output bytes 4j..4j+3 (pre-swizzle)
+    uint32_t* stg;          // [stg_words]   macroblock bitstreams, each from a dword boundary, same bit order as `out`
+    uint32_t* rec;          // [nmb]         per macroblock (encode order): staging dword offset | stream bits << 16
+    uint32_t* mb_off;       // [nmb]         bit offset of each macroblock in the frame's stream
+    int16_t* dcv;           // [nmb*6]       per block, encode order: v2 the quantised DC; v3 the quantised DC, then (after the
+                            //               chain scan) the DPCM delta -- codes are derived where they are needed
+    uint16_t* ac_len16;     // [BS_LUT_SIZE] bits | refinement deficit << 8
+    uint32_t* ac_code;      // [BS_LUT_SIZE] bits << 24 | deficit << 17 | code
     uint8_t* dc_plen;       // [16]
     uint8_t* dc_prefix;     // [16]
-    int16_t* tiles;         // per-wave DCT staging
-    float2* qtab;           // [kScalesPerPass][64]  {1/(2 quant scale), 0.5 + 0.5/(2 quant scale)} for the current pass
-    int* pass_bits;         // [kScalesPerPass] AC bits of the whole frame per scale
-    int* scalars;           // [8]: 0 dc_bits, 1 chosen scale, 2 chosen index in pass, 3 nnz, 4 total bits
+    int16_t* tiles;         // per-wave DCT staging / code list
+    int* scalars;           // [S_COUNT]
 };
 
-constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile (the pixel tile aliases the latter)
+static_assert(sizeof(MdecSearch) == 56 && (S_SEARCH % 2) == 0, "MdecSearch lives in scalars[S_SEARCH..+14)");
+constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile
+static_assert(kWaveTileBytes >= 384 * 4, "the per-wave code list (384 entries) aliases the tiles");
 
-__host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int waves) {
+__host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_words, int waves) {
     size_t b = 0;
     b += (size_t)out_words * 4;
-    b += (size_t)nmb * kScalesPerPass * 2;
+    b += (size_t)stg_words * 4;
+    b += (size_t)nmb * 4;         // rec
+    b += (size_t)nmb * 4;         // mb_off
+    b += (size_t)nmb * 6 * 2;     // dcv
     b = (b + 3) & ~(size_t)3;
-    b += (size_t)nmb * 4;
-    b += (size_t)nmb * 6 * 2;
-    b = (b + 3) & ~(size_t)3;
-    b += BS_LUT_SIZE;             // ac_len
+    b += BS_LUT_SIZE * 2;         // ac_len16
     b = (b + 3) & ~(size_t)3;
     b += BS_LUT_SIZE * 4;         // ac_code
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
     b += (size_t)waves * kWaveTileBytes;
-    b += (size_t)kScalesPerPass * 64 * 8;   // qtab
-    b += 64;                      // pass_bits + scalars
-    return b;
+    b += (size_t)S_COUNT * 4;
+    return (b + 15) & ~(size_t)15;
 }
 
-__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int waves) {
+__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg_words, int waves) {
     Lds L;
     size_t b = 0;
     L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
-    L.mb_bits = (uint16_t*)(base + b);    b += (size_t)nmb * kScalesPerPass * 2;  b = (b + 3) & ~(size_t)3;
+    L.stg = (uint32_t*)(base + b);        b += (size_t)stg_words * 4;
+    L.rec = (uint32_t*)(base + b);        b += (size_t)nmb * 4;
     L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
     L.dcv = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
-    L.ac_len = (uint8_t*)(base + b);      b += BS_LUT_SIZE;                        b = (b + 3) & ~(size_t)3;
+    L.ac_len16 = (uint16_t*)(base + b);   b += BS_LUT_SIZE * 2;                    b = (b + 3) & ~(size_t)3;
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
     L.tiles = (int16_t*)(base + b);       b += (size_t)waves * kWaveTileBytes;
-    L.qtab = (float2*)(base + b);         b += (size_t)kScalesPerPass * 64 * 8;
-    L.pass_bits = (int*)(base + b);       b += kScalesPerPass * 4;
     L.scalars = (int*)(base + b);
     return L;
 }
@@ -220,13 +248,29 @@ struct LaneConst {
     int lane_m64;       // lane - 64
 };
 
-// One block at one scale, branch-free.  `two_abs_f` = float(2|n|), 0 on lane 0 (the DC slot never carries an
-// AC code); `inv2d` = 1/(2 quant scale), `bias` = 0.5 + 0.5 * inv2d.
-//   floor((2|n| + d) / 2d) with d / 2d = 0.5 folded into the addend: trunc(fma(2|n|, 1/2d, 0.5 + 0.5/2d)).
-//   Same argument as quant_level(): the exact value is >= 0.5/2d away from every integer, the computed one is
-//   within (2|n| + d) * 1.5 * 2^-23 / 2d + 2^-25 of it (tests/test_mdec_oracle.py checks every operand).
-__device__ __forceinline__ int quant_mag(float two_abs_f, float inv2d, float bias) {
-    return (int)__builtin_fmaf(two_abs_f, inv2d, bias);
+// ---------------------------------------------------------------------------------------------
+// Quantiser.  The reference computes (int)round((double)n / (double)d)  (mdec.c:438): round half
+// away from zero, i.e.  sgn(n) * floor((2|n| + d) / (2d)) = sgn(n) * floor(|n| / d + 1/2).  With
+// N = 2|n| + d and D = 2d, floor(N / D) == floor((N + 0.5) / D), and (N + 0.5) / D is at least 0.5 / D away
+// from every integer.  The kernel evaluates  trunc(fma(|n|, 1/d, 0.5 + 0.25/d))  in fp32 -- the same real
+// number -- with 1/d the correctly rounded reciprocal: the result is within (N + 0.5) * 1.5 * 2^-23 / D +
+// 2^-25 of it, which is < 0.5 / D for every reachable operand (N < 2^17), so truncation gives the exact
+// floor (tests/test_mdec_oracle.py::test_fp32_reciprocal_quantiser_is_exact checks every operand, also
+// with the reciprocal off by +-2 ulp).  `cf` = float(n) (the sign is dropped by the fma's |.| modifier),
+// 0 on lane 0 (the DC slot never carries an AC code).
+// ---------------------------------------------------------------------------------------------
+struct QuantK {
+    float inv;    // 1 / (quant * scale)
+    float bias;   // 0.5 + 0.25 / (quant * scale)
+};
+__device__ __forceinline__ QuantK make_quant(int quant, int scale) {
+    QuantK k;
+    k.inv = 1.0f / (float)(quant * scale);      // IEEE division
+    k.bias = 0.5f + 0.25f * k.inv;
+    return k;
+}
+__device__ __forceinline__ int quant_mag(float cf, const QuantK& k) {
+    return (int)__builtin_fmaf(__builtin_fabsf(cf), k.inv, k.bias);
 }
 
 // number of zero coefficients between this lane and the previous non-zero one (bit 0 of the mask, the
@@ -244,13 +288,20 @@ __device__ __forceinline__ int lut_index(int q, int run) {
     return (int)__umul24(qc, (unsigned)BS_LUT_W) + run;     // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
 }
 
-// AC bits of one block at the four scales of a pass; two 16-bit counters per accumulator register.
-// (the DC slot of every block is stored as 0, so lane 0 never produces a level)
-// `live` (wave-uniform) has bit s set while scale s of the pass can still fit: like the reference, which stops an
-// attempt at the first overflow (mdec.c:323-325,689-706), a scale whose running frame total already exceeds the budget
-// is not evaluated any further -- its verdict cannot change.
+// AC code lengths of the six blocks of a macroblock at one scale: returns per lane  sum(bits) | sum(deficit) << 8
+// (<= 6 * 22 and <= 6 * 9: the fields cannot carry into each other)
+__device__ __forceinline__ int count_mb(const float (&cf)[6], const QuantK& k, const LaneConst& lc, const uint16_t* ac_len16) {
+    int acc = 0;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        const int q = quant_mag(cf[b], k);
+        acc += (int)ac_len16[lut_index(q, run_before(wave::ballot(q != 0), lc))];
+    }
+    return acc;
+}
+
 // DC code of one block: v2 = the 10-bit value (mdec.c:451-453); v3 = VLC of the DPCM delta: size class = magnitude
-// bits, then a sign-dependent offset (mdec.c:285-318).  `tab` = {plen[2][8], prefix[2][8]} in LDS.
+// bits, then a sign-dependent offset (mdec.c:285-318).
 template <int CODEC>
 __device__ __forceinline__ void dc_code(int v, int luma, const uint8_t* plen, const uint8_t* prefix, int& len, uint32_t& code) {
     if (CODEC == 0) {
@@ -269,104 +320,89 @@ __device__ __forceinline__ void dc_code(int v, int luma, const uint8_t* plen, co
     }
 }
 
-template <int LIVE>
-__device__ __forceinline__ void count_block4_live(float two_abs, const float2& k0, const float2& k1, const float2& k2,
-                                                  const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int& acc01,
-                                                  int& acc23) {
-    // straight-line code for one set of live scales: the compiler interleaves the independent chains
-    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-    if (LIVE & 1) { const int q = quant_mag(two_abs, k0.x, k0.y); i0 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
-    if (LIVE & 2) { const int q = quant_mag(two_abs, k1.x, k1.y); i1 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
-    if (LIVE & 4) { const int q = quant_mag(two_abs, k2.x, k2.y); i2 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
-    if (LIVE & 8) { const int q = quant_mag(two_abs, k3.x, k3.y); i3 = lut_index(q, run_before(wave::ballot(q != 0), lc)); }
-    int a01 = 0, a23 = 0;
-    if (LIVE & 1) a01 = (int)ac_len[i0];
-    if (LIVE & 2) a01 |= (int)ac_len[i1] << 16;
-    if (LIVE & 4) a23 = (int)ac_len[i2];
-    if (LIVE & 8) a23 |= (int)ac_len[i3] << 16;
-    if (LIVE & 3) acc01 += a01;
-    if (LIVE & 12) acc23 += a23;
+// ---------------------------------------------------------------------------------------------
+// Macroblock visiting order.  A macroblock's bitstream is built independently of its position in the frame's stream
+// (staging + merge below), so the visiting order is free: wavefront w takes the macroblocks w, w + W, w + 2W, ... in
+// RASTER order, i.e. at any time the W wavefronts of a group work on W horizontally adjacent macroblocks and share
+// the frame's cache lines (a 128-byte line spans 8 macroblocks of a luma row).  The index in ENCODE order (fx outer,
+// fy inner, mdec.c:689-690) is what the stream layout needs.  (fx, fy) advance incrementally, no divisions in the loop.
+// ---------------------------------------------------------------------------------------------
+struct MbCursor {
+    int fx, fy;
+};
+__device__ __forceinline__ MbCursor mb_cursor(int raster_index, int nx) {
+    MbCursor c;
+    c.fy = raster_index / nx;
+    c.fx = raster_index - c.fy * nx;
+    return c;
+}
+template <int WAVES>
+__device__ __forceinline__ void mb_advance(MbCursor& c, int nx) {
+    c.fx += WAVES;
+    while (c.fx >= nx) { c.fx -= nx; c.fy++; }
 }
 
-__device__ __forceinline__ void count_block4(int c, const float2& k0, const float2& k1, const float2& k2,
-                                             const float2& k3, const LaneConst& lc, const uint8_t* ac_len, int live,
-                                             int& acc01, int& acc23) {
-    static_assert(kScalesPerPass == 4, "count_block4 evaluates 4 scales");
-    const float two_abs = (float)(2 * (c < 0 ? -c : c));
-    // bits(s) falls with s on ordinary material, so scales die lowest-first: those sets get straight-line code
-    switch (live) {
-    case 0xF: count_block4_live<0xF>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
-    case 0xE: count_block4_live<0xE>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
-    case 0xC: count_block4_live<0xC>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
-    case 0x8: count_block4_live<0x8>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23); break;
-    case 0x0: break;
-    default:
-        if (live & 1) count_block4_live<1>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
-        if (live & 2) count_block4_live<2>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
-        if (live & 4) count_block4_live<4>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
-        if (live & 8) count_block4_live<8>(two_abs, k0, k1, k2, k3, lc, ac_len, acc01, acc23);
-        break;
+// Source bytes of a macroblock (mdec.c:619-633).  Lane t < 48 = (block t>>3, row t&7) fetches its own
+// 8 pixels straight from the frame (no LDS staging): a luma row is 8 contiguous bytes, a chroma row is
+// 16 bytes of interleaved Cr,Cb (NV21: Cr at even bytes, Cb at odd).  All offsets are 32-bit (a frame is
+// < 2^31 bytes).
+struct PixelLane {
+    uint32_t lane_off;       // offset of this lane's pixel row inside macroblock (0, 0)
+    uint32_t hi_off;         // chroma rows are 16 bytes long: second half
+    uint32_t mb_row_step;    // bytes per macroblock row for this lane's plane
+    uint32_t sel[4];         // v_perm selectors building (p0,p1) (p2,p3) (p7,p6) (p5,p4) as int16 pairs
+};
+__device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
+    PixelLane p;
+    const int blk = lane >> 3, r8 = lane & 7;
+    const bool is_chroma = blk < 2;
+    if (is_chroma) p.lane_off = (uint32_t)W * (uint32_t)H + (uint32_t)r8 * (uint32_t)W;
+    else p.lane_off = ((uint32_t)(((blk - 2) >> 1) * 8 + r8)) * (uint32_t)W + (uint32_t)((blk - 2) & 1) * 8u;
+    if (lane >= 48) p.lane_off = 0;                 // idle lanes read the frame's first bytes (unused)
+    p.hi_off = is_chroma ? 8u : 0u;
+    p.mb_row_step = (is_chroma ? 8u : 16u) * (uint32_t)W;
+    // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte pool {lo: 0..3, hi: 4..7}; 0x0C = 0x00.
+    // Pools (see load_pairs): A = {plo.x, plo.y}, B = {plo.y, phi.x}, C = {plo.y, phi.y}.
+    //   luma: the row's 8 pixels are plo.x, plo.y.  chroma: 16 bytes plo.x, plo.y, phi.x, phi.y with this
+    //   block's samples at even (Cr, blk 0) or odd (Cb, blk 1) bytes.
+    if (!is_chroma) {
+        p.sel[0] = 0x0C010C00u;    // (p0, p1) = A bytes 0, 1
+        p.sel[1] = 0x0C030C02u;    // (p2, p3) = A bytes 2, 3
+        p.sel[2] = 0x0C020C03u;    // (p7, p6) = C bytes 3, 2  (plo.y)
+        p.sel[3] = 0x0C000C01u;    // (p5, p4) = B bytes 1, 0  (plo.y)
+    } else {
+        const uint32_t o = (uint32_t)blk;   // 0: even bytes, 1: odd bytes
+        p.sel[0] = 0x0C020C00u + o * 0x00010001u;   // (p0, p1) = plo.x bytes 0, 2 (+o)
+        p.sel[1] = 0x0C060C04u + o * 0x00010001u;   // (p2, p3) = plo.y bytes 0, 2 = A bytes 4, 6
+        p.sel[2] = 0x0C040C06u + o * 0x00010001u;   // (p7, p6) = phi.y bytes 2, 0 = C bytes 6, 4
+        p.sel[3] = 0x0C040C06u + o * 0x00010001u;   // (p5, p4) = phi.x bytes 2, 0 = B bytes 6, 4
     }
-}
-
-// which scales of the pass are still below the AC-bit limit (wave-uniform bit mask)
-__device__ __forceinline__ int live_scales(const int4& totals, int limit_ac) {
-    static_assert(kScalesPerPass == 4, "one int4 of running totals");
-    const int p0 = __builtin_amdgcn_readfirstlane(totals.x), p1 = __builtin_amdgcn_readfirstlane(totals.y);
-    const int p2 = __builtin_amdgcn_readfirstlane(totals.z), p3 = __builtin_amdgcn_readfirstlane(totals.w);
-    return (p0 <= limit_ac ? 1 : 0) | (p1 <= limit_ac ? 2 : 0) | (p2 <= limit_ac ? 4 : 0) | (p3 <= limit_ac ? 8 : 0);
-}
-
-// per-macroblock sums of the packed counters -> LDS (per macroblock for the offset scan, per frame for rate control)
-__device__ __forceinline__ void count_finish4(int acc01, int acc23, int lane, uint16_t* mb_bits_slot, int* pass_bits) {
-    const int t01 = wave::reduce_add(acc01);
-    const int t23 = wave::reduce_add(acc23);
-    if (lane == 0) {
-        uint2 v;
-        v.x = (uint32_t)t01;
-        v.y = (uint32_t)t23;
-        *(uint2*)mb_bits_slot = v;
-        atomicAdd(&pass_bits[0], t01 & 0xFFFF);
-        atomicAdd(&pass_bits[1], (int)((unsigned)t01 >> 16));
-        atomicAdd(&pass_bits[2], t23 & 0xFFFF);
-        atomicAdd(&pass_bits[3], (int)((unsigned)t23 >> 16));
-    }
-}
-
-__device__ __forceinline__ void fill_qtab(float2* qtab, int tid, int lane, int scale0) {
-    // quantiser constants of a pass, once per workgroup (IEEE division, not per macroblock)
-    if (tid < kScalesPerPass * 64) {
-        const float r = 1.0f / (float)(2 * (int)c_quant_zz[lane] * (scale0 + (tid >> 6)));
-        qtab[tid] = make_float2(r, 0.5f + 0.5f * r);
-    }
+    return p;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register budget: the kernel is compiled for 8 wavefronts per SIMD (<= 64 VGPRs), i.e. two frames in
+// Register budget: the small shape is compiled for 6 wavefronts per SIMD (<= 80 VGPRs), i.e. two frames in
 // flight per CU.  The hot path is latency-bound (LDS look-ups, DPP scans, ballots), so it is written
-// as short per-block bodies that rely on 8-way wave interleaving rather than on wide unrolled bodies
-// that would need > 64 registers.  The three per-macroblock loops are: (A) DCT -> slab, (B) bit counts
-// for kScalesPerPass scales from the slab, (C) emit at the chosen scale from the slab.
+// as short per-block bodies that rely on wave interleaving rather than on wide unrolled bodies.
 // ---------------------------------------------------------------------------------------------
 template <int CODEC, int WAVES, int OCC>
 __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(const FrameJob job) {
     constexpr int kWavesPerGroup = WAVES;
     constexpr int kThreads = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds L = carve(smem, job.nmb, job.out_words, WAVES);
+    const Lds L = carve(smem, job.nmb, job.out_words, job.stg_words, WAVES);
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
     const int nblk = nmb * 6;
-
-    PhaseClock clk;
-    clk.start(job.timing);
+    constexpr int kPilotPerWave = WAVES == kWavesLarge ? 2 : 1;
+    const int n_pilot = nmb < kWavesPerGroup * kPilotPerWave ? nmb : kWavesPerGroup * kPilotPerWave;
 
     // ---- once per workgroup: LUTs into LDS, per-lane constants
     for (int i = tid; i < BS_LUT_SIZE; i += kThreads) {
-        L.ac_len[i] = c_ac_len[i];
+        L.ac_len16[i] = c_ac_len16[i];
         L.ac_code[i] = c_ac_code[i];
     }
     if (tid < 16) {
@@ -378,275 +414,493 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     lc.below = (1ull << lane) - 1ull;
     lc.lane_m64 = lane - 64;
 
+    int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
+    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
+    uint32_t* clist = (uint32_t*)tileT;                                // code list of a macroblock (aliases both tiles)
+
     // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3);
-    // the eight scan positions are packed one byte each into two registers
-    uint32_t zpos_lo = 0, zpos_hi = 0;
+    // the eight LDS byte addresses (relative to the wave's zig-zag tile) are packed two per register
+    uint32_t zaddr[4];
     {
         uint8_t* inv = (uint8_t*)L.tiles;   // temporary use before the tiles are live
         if (tid < 64) inv[c_zagzig[tid]] = (uint8_t)tid;
         __syncthreads();
+        const int zb = (lane >> 3) * kZStride;
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            zpos_lo |= (uint32_t)inv[v * 8 + (lane & 7)] << (8 * v);
-            zpos_hi |= (uint32_t)inv[(v + 4) * 8 + (lane & 7)] << (8 * v);
+            const uint32_t a0 = (uint32_t)(zb + inv[(2 * v) * 8 + (lane & 7)]) * 2u;
+            const uint32_t a1 = (uint32_t)(zb + inv[(2 * v + 1) * 8 + (lane & 7)]) * 2u;
+            zaddr[v] = a0 | (a1 << 16);
         }
         __syncthreads();
     }
+    const PixelLane pl = pixel_lane(lane, W, H);
+    const int blk = lane >> 3, r8 = lane & 7;
 
-    int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
-    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
+    // Two groups share a CU in the small shape.  The SIMD arbiter serves the OLDER wavefront first (priority, then age),
+    // so left alone the group that arrived first runs at full speed and its partner on the leftovers -- and the partner
+    // ends up finishing its last frame alone on a half-empty CU.  Wave slot numbers tell the two groups apart (the
+    // first group on a SIMD holds the low slots); the groups take turns at raised priority, one macroblock at a time.
+    const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
+    const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
+    unsigned long long t_start = 0;
+    int n_done = 0;
+    if (job.stats) t_start = wall_clock64();
+    for (;;) {
+        // ---- next frame: tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
+        if (tid == 0) L.scalars[S_FRAME] = (int)atomicAdd(&job.ticket[0], 1u);
+        __syncthreads();
+        const int f = L.scalars[S_FRAME];
+        if (f >= job.n_frames) break;
 
-    int16_t* slab = job.coef_slab + (size_t)blockIdx.x * nmb * 384;
-
-    clk.mark(7);   // per-workgroup prologue
-
-    for (int f = (int)blockIdx.x; f < job.n_frames; f += (int)gridDim.x) {
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
         int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
-        // per-frame budgets live in device memory the host cannot vet: a budget outside [8, the context's maximum]
-        // is treated as "nothing fits" (result quant_scale 64, no bytes written) instead of overrunning the staging
-        const bool bad_budget = max_size < 8 || max_size > (job.out_words - 2) * 4;
+        // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
+        // the output row)] is treated as "nothing fits" (result quant_scale 64, no bytes written)
+        const bool bad_budget = max_size < 8 || max_size > (job.out_words - 2) * 4 || (size_t)max_size > job.out_stride;
         if (bad_budget) max_size = 8;
         const int max_words = (max_size + 3) >> 2;
-        // a scale is hopeless once its AC bits alone exceed what the budget leaves after the cheapest possible
-        // DC codes (v2: 10 bits, v3: >= 2 bits), the end-of-block codes and the end-of-frame code:
-        // fits <=> 8 + 2*ceil(bits/16) <= max_size <=> bits <= 16 * floor((max_size - 8) / 2)
-        const int limit_ac = 16 * ((max_size - 8) >> 1) - (nblk * ((CODEC == 0 ? 10 : 2) + 2) + 10);
+        // fits <=> 8 + 2*ceil(bits/16) <= max_size <=> bits <= 16 * floor((max_size - 8) / 2)   (mdec.c:321-333 in closed form)
+        const int limit_bits = 16 * ((max_size - 8) >> 1);
 
         // ---- reset per-frame state
         for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
-        if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
-        if (tid < 8) L.scalars[tid] = 0;
-        fill_qtab(L.qtab, tid, lane, 1);
+        for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
+        if (tid < S_COUNT && tid != S_FRAME) L.scalars[tid] = 0;
         __syncthreads();
-        clk.mark(0);
 
         // =====================================================================================
-        // (A) DCT of every macroblock -> coefficient slab (zig-zag order) + quantised DC, fused with the first
-        //     count pass (scales 1..kScalesPerPass) while the coefficients are still in LDS
+        // v3 / v3dc: the DC terms come first, because a block's DC code depends on the previous block of the same
+        // component (mdec.c:454-479).  The DC coefficient of the islow DCT is exactly the sum of the block's 64
+        // level-shifted samples (row pass 16 * row sum, column pass (16 * sum + 8) >> 4), so a pass of byte sums does it.
         // =====================================================================================
-        {
-            // Source bytes of a macroblock (mdec.c:619-633).  Lane t < 48 = (block t>>3, row t&7) fetches its own
-            // 8 pixels straight from the frame (no LDS staging): a luma row is 8 contiguous bytes, a chroma row is
-            // 16 bytes of interleaved Cr,Cb (NV21: Cr at even bytes, Cb at odd).  All offsets are 32-bit (a frame is
-            // < 2^31 bytes); (fx, fy) advance incrementally, no divisions.
-            const int blk = lane >> 3, r8 = lane & 7;
-            const bool is_chroma = blk < 2;
-            uint32_t lane_off;      // offset of this lane's pixel row inside macroblock (0, 0)
-            if (is_chroma) lane_off = (uint32_t)W * (uint32_t)H + (uint32_t)r8 * (uint32_t)W;
-            else lane_off = ((uint32_t)(((blk - 2) >> 1) * 8 + r8)) * (uint32_t)W + (uint32_t)((blk - 2) & 1) * 8u;
-            if (lane >= 48) lane_off = 0;                       // idle lanes read the frame's first bytes (unused)
-            const uint32_t hi_off = is_chroma ? 8u : 0u;        // chroma rows are 16 bytes long
-            const uint32_t mb_row_step = (is_chroma ? 8u : 16u) * (uint32_t)W;
-            const uint32_t perm_sel = blk == 0 ? 0x06040200u : 0x07050301u;   // even (Cr) / odd (Cb) bytes of a dword pair
-            int fy = wid / nx, fx = wid - fy * nx;              // once per frame per wavefront
-            uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
-            if (wid < nmb) {
-                const uint8_t* p = frame + (lane_off + (uint32_t)fy * mb_row_step + (uint32_t)fx * 16u);
-                plo = *(const uint2*)p;
-                phi = *(const uint2*)(p + hi_off);
-            }
+        if (CODEC != 0) {
+            MbCursor mc = mb_cursor(wid, nx);
             for (int m = wid; m < nmb; m += kWavesPerGroup) {
-                const int mbe = fx * ny + fy;   // encode order: fx outer, fy inner (mdec.c:689-690)
-                // which scales are still in the race: one 16-byte LDS read, issued early (a slightly stale view only
-                // means a dead scale is evaluated once more)
-                const int4 totals = *(const int4*)L.pass_bits;
-
-                // -- this lane's 8 pixels as two dwords
-                uint2 px;
-                px.x = is_chroma ? __builtin_amdgcn_perm(plo.y, plo.x, perm_sel) : plo.x;
-                px.y = is_chroma ? __builtin_amdgcn_perm(phi.y, phi.x, perm_sel) : plo.y;
-                // -- prefetch the next macroblock of this wavefront while this one is transformed
-                {
-                    fx += kWavesPerGroup;
-                    while (fx >= nx) { fx -= nx; fy++; }
-                    if (m + kWavesPerGroup < nmb) {
-                        const uint8_t* p = frame + (lane_off + (uint32_t)fy * mb_row_step + (uint32_t)fx * 16u);
-                        plo = *(const uint2*)p;
-                        phi = *(const uint2*)(p + hi_off);
-                    }
-                }
-
-                int d[8];
-                if (lane < 48) {
-                    // -- row pass: lane = (block, row)
-                    d[0] = (int)(px.x & 0xFF) - 128;
-                    d[1] = (int)((px.x >> 8) & 0xFF) - 128;
-                    d[2] = (int)((px.x >> 16) & 0xFF) - 128;
-                    d[3] = (int)(px.x >> 24) - 128;
-                    d[4] = (int)(px.y & 0xFF) - 128;
-                    d[5] = (int)((px.y >> 8) & 0xFF) - 128;
-                    d[6] = (int)((px.y >> 16) & 0xFF) - 128;
-                    d[7] = (int)(px.y >> 24) - 128;
-                    fdct8<false>(d);
-#pragma unroll
-                    for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
-                }
-                wave_sync();
-                if (lane < 48) {
-                    // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
-                    const int4 q = *(const int4*)&tileT[blk * kTileStride + r8 * 8];
-                    d[0] = (int)(int16_t)(q.x & 0xFFFF);
-                    d[1] = q.x >> 16;
-                    d[2] = (int)(int16_t)(q.y & 0xFFFF);
-                    d[3] = q.y >> 16;
-                    d[4] = (int)(int16_t)(q.z & 0xFFFF);
-                    d[5] = q.z >> 16;
-                    d[6] = (int)(int16_t)(q.w & 0xFFFF);
-                    d[7] = q.w >> 16;
-                    fdct8<true>(d);
-                    // -- column 0 holds the block's DC term in d[0]: quantise it here, and store 0 in its place so that
-                    //    the AC path (here, in later count passes and in emit) sees "no coefficient" at scan position 0
-                    if (r8 == 0) {
-                        const int dc = quant_dc(d[0]);
-                        L.dcv[mbe * 6 + blk] = (int16_t)dc;     // v3: raw value for the DPCM chain below
-                        d[0] = 0;
-                    }
-#pragma unroll
-                    for (int v = 0; v < 8; v++) {
-                        const uint32_t zp = ((v < 4 ? zpos_lo : zpos_hi) >> (8 * (v & 3))) & 0xFFu;
-                        tileZ[blk * kZStride + zp] = (int16_t)d[v];
-                    }
-                }
-                wave_sync();
-                // -- lane k owns zig-zag position k of each of the 6 blocks: to the slab, and counted at scales 1..4
-                int16_t* dst = slab + ((unsigned)mbe * 384u + (unsigned)lane);
-                {
-                    const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
-                    int acc01 = 0, acc23 = 0;
-                    const int live = live_scales(totals, limit_ac);
-#pragma unroll 1
-                    for (int b = 0; b < 6; b++) {
-                        const int c = tileZ[b * kZStride + lane];
-                        dst[b * 64] = (int16_t)c;
-                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, live, acc01, acc23);
-                    }
-                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], L.pass_bits);
-                }
-                wave_sync();   // the zig-zag tile is rewritten by the next iteration
-            }
-        }
-        __syncthreads();
-        clk.mark(1);
-
-        // =====================================================================================
-        // DC: v2 = 10 bits per block; v3 = DPCM chain per component in encode order (mdec.c:454-479)
-        // =====================================================================================
-        if (CODEC == 0) {
-            if (tid == 0) L.scalars[0] = 10 * nblk;
-        } else if (wid < 3) {
-            // wave 0: Cr chain, wave 1: Cb chain, wave 2: the Y chain (4 blocks per macroblock).
-            // Element i maps last -> new_last:
-            //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
-            //   dc % 4 == 2 : last < dc ? dc + 2 : dc - 2           (tie, rounds away from zero)
-            // Both are step functions (thr, lo, hi); composition g(f(x)) = (thr_f, g(lo_f), g(hi_f)),
-            // so the chain is an inclusive scan under composition.
-            const int count = wid == 2 ? 4 * nmb : nmb;
-            int carry = 0, bits = 0;
-            for (int base = 0; base < count; base += 64) {
-                const int i = base + lane;
-                const bool live = i < count;
-                const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
-                const int dc = live ? (int)L.dcv[idx] : 0;
-                int thr, lo, hi;
-                if ((dc & 3) == 2) {
-                    thr = dc; lo = dc + 2; hi = dc - 2;
+                const uint8_t* p = frame + (pl.lane_off + (uint32_t)mc.fy * pl.mb_row_step + (uint32_t)mc.fx * 16u);
+                const uint2 plo = *(const uint2*)p;
+                const uint2 phi = *(const uint2*)(p + pl.hi_off);
+                uint32_t a, b;
+                if (blk < 2) {
+                    const uint32_t m8 = blk == 0 ? 0x00FF00FFu : 0xFF00FF00u;
+                    a = __builtin_amdgcn_sad_u8(plo.x & m8, 0u, __builtin_amdgcn_sad_u8(plo.y & m8, 0u, 0u));
+                    b = __builtin_amdgcn_sad_u8(phi.x & m8, 0u, __builtin_amdgcn_sad_u8(phi.y & m8, 0u, 0u));
                 } else {
-                    const int a = dc < 0 ? -dc : dc;
-                    const int rq = ((a + 2) >> 2) << 2;
-                    thr = 0; lo = hi = dc < 0 ? -rq : rq;
+                    a = __builtin_amdgcn_sad_u8(plo.x, 0u, 0u);
+                    b = __builtin_amdgcn_sad_u8(plo.y, 0u, 0u);
                 }
-                if (!live) { thr = -100000; lo = hi = 0; }   // dead lanes sit after all live ones, never feed them
+                int s = (int)(a + b);
+                s += wave::dpp_or_zero<0xB1, 0xF, 0xF>(s);    // quad_perm [1,0,3,2]
+                s += wave::dpp_or_zero<0x4E, 0xF, 0xF>(s);    // quad_perm [2,3,0,1]
+                s += wave::dpp_or_zero<0x141, 0xF, 0xF>(s);   // row_half_mirror: all 8 lanes of the block hold its sum
+                if (r8 == 0 && lane < 48) L.dcv[(mc.fx * ny + mc.fy) * 6 + blk] = (int16_t)quant_dc(s - 64 * 128);
+                mb_advance<kWavesPerGroup>(mc, nx);
+            }
+            __syncthreads();
+            if (wid < 3) {
+                // wave 0: Cr chain, wave 1: Cb chain, wave 2: the Y chain (4 blocks per macroblock).
+                // Element i maps last -> new_last:
+                //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
+                //   dc % 4 == 2 : last < dc ? dc + 2 : dc - 2           (tie, rounds away from zero)
+                // Both are step functions (thr, lo, hi); composition g(f(x)) = (thr_f, g(lo_f), g(hi_f)),
+                // so the chain is an inclusive scan under composition.
+                const int count = wid == 2 ? 4 * nmb : nmb;
+                int carry = 0, bits = 0;
+                for (int base = 0; base < count; base += 64) {
+                    const int i = base + lane;
+                    const bool live = i < count;
+                    const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
+                    const int dc = live ? (int)L.dcv[idx] : 0;
+                    int thr, lo, hi;
+                    if ((dc & 3) == 2) {
+                        thr = dc; lo = dc + 2; hi = dc - 2;
+                    } else {
+                        const int a = dc < 0 ? -dc : dc;
+                        const int rq = ((a + 2) >> 2) << 2;
+                        thr = 0; lo = hi = dc < 0 ? -rq : rq;
+                    }
+                    if (!live) { thr = -100000; lo = hi = 0; }   // dead lanes sit after all live ones, never feed them
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int pthr = __shfl_up(thr, off, 64);
-                    const int plo = __shfl_up(lo, off, 64);
-                    const int phi = __shfl_up(hi, off, 64);
-                    if (lane >= off) {
-                        // me(prev(x)): apply my current (thr, lo, hi) to the predecessor's two outputs
-                        const int nlo = plo < thr ? lo : hi;
-                        const int nhi = phi < thr ? lo : hi;
-                        thr = pthr; lo = nlo; hi = nhi;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int pthr = __shfl_up(thr, off, 64);
+                        const int plo = __shfl_up(lo, off, 64);
+                        const int phi = __shfl_up(hi, off, 64);
+                        if (lane >= off) {
+                            // me(prev(x)): apply my current (thr, lo, hi) to the predecessor's two outputs
+                            const int nlo = plo < thr ? lo : hi;
+                            const int nhi = phi < thr ? lo : hi;
+                            thr = pthr; lo = nlo; hi = nhi;
+                        }
+                    }
+                    const int cur = carry < thr ? lo : hi;            // last value after element i
+                    int prev = __shfl_up(cur, 1, 64);
+                    if (lane == 0) prev = carry;
+                    int delta = (cur - prev) >> 2;                      // exact: both multiples of 4
+                    if (CODEC == 2) {                                   // v3dc wrap (mdec.c:469-474)
+                        if (delta < -0x80) delta += 0x100;
+                        else if (delta > 0x80) delta -= 0x100;
+                    }
+                    int dlen;
+                    uint32_t dcode;
+                    dc_code<CODEC>(delta, wid == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
+                    if (live) {
+                        L.dcv[idx] = (int16_t)delta;
+                        bits += dlen;
+                    }
+                    carry = __shfl(cur, 63, 64);
+                }
+                bits = wave::reduce_add(bits);
+                if (lane == 0) atomicAdd(&L.scalars[S_DC_BITS], bits);
+            }
+            __syncthreads();
+        }
+        const int dc_bits = CODEC == 0 ? 10 * nblk : L.scalars[S_DC_BITS];
+        const int fixed_bits = dc_bits + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
+
+        // =====================================================================================
+        // One pass over the frame's macroblocks: DCT, then (optionally) AC bits at `count_scale`, then (optionally) the
+        // macroblock's bitstream at `emit_scale` into the staging area.  `pilot` runs the DCT of the wavefront's first
+        // macroblock only and leaves its coefficients in cf[]; the following pass picks them up (`resume`).
+        // =====================================================================================
+        float cf[6];            // this lane's coefficient of each block of the current macroblock, as float; lane 0 holds 0
+        MbCursor mc;
+        uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
+
+        auto fetch = [&](const MbCursor& c) {
+            const uint8_t* p = frame + (pl.lane_off + (uint32_t)c.fy * pl.mb_row_step + (uint32_t)c.fx * 16u);
+            plo = *(const uint2*)p;
+            phi = *(const uint2*)(p + pl.hi_off);
+        };
+        // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
+        auto dct_mb = [&](int mbe_cur, bool have_next, int& next_out) {
+            const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[0]);
+            const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[1]);
+            const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, pl.sel[2]);
+            const uint32_t R1 = __builtin_amdgcn_perm(phi.x, plo.y, pl.sel[3]);
+            if (have_next) {               // mc points at the wavefront's next macroblock
+                fetch(mc);
+                next_out = mc.fx * ny + mc.fy;
+                mb_advance<kWavesPerGroup>(mc, nx);
+            }
+            int d[8];
+            if (lane < 48) {
+                // -- row pass: lane = (block, row)
+                fdct8_pk<false>(P0, P1, R0, R1, d);
+#pragma unroll
+                for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+            }
+            wave_sync();
+            if (lane < 48) {
+                // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
+                const uint4 q = *(const uint4*)&tileT[blk * kTileStride + r8 * 8];
+                fdct8_pk<true>(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+                // -- column 0 holds the block's DC term in d[0]: v2 quantises it here; 0 is stored in its place so that
+                //    the AC path sees "no coefficient" at scan position 0
+                if (r8 == 0) {
+                    if (CODEC == 0) L.dcv[mbe_cur * 6 + blk] = (int16_t)quant_dc(d[0]);
+                    d[0] = 0;
+                }
+                char* zb = (char*)tileZ;
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const uint32_t a = (v & 1) ? (zaddr[v >> 1] >> 16) : (zaddr[v >> 1] & 0xFFFFu);
+                    *(int16_t*)(zb + a) = (int16_t)d[v];
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int b = 0; b < 6; b++) cf[b] = (float)(int)tileZ[b * kZStride + lane];
+            wave_sync();     // the tiles are free again (the code list aliases them)
+        };
+
+        // ---- pilot: kPilotPerWave macroblocks per wavefront, spread evenly over the frame in raster order; their AC bits
+        //      at a few scales, scaled up to the frame, predict the answer
+        float cfp[kPilotPerWave][6];
+        int next_mbe = 0;            // the macroblock (encode order) whose pixels are in (plo, phi)
+#pragma unroll
+        for (int i = 0; i < kPilotPerWave; i++) {
+            const int pi = wid * kPilotPerWave + i;
+            if (pi < n_pilot) {
+                mc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
+                fetch(mc);
+                dct_mb(mc.fx * ny + mc.fy, false, next_mbe);
+            }
+#pragma unroll
+            for (int b = 0; b < 6; b++) cfp[i][b] = pi < n_pilot ? cf[b] : 0.0f;
+        }
+        if (tid == 0) {
+            L.scalars[S_PILOT_N] = 4;
+            L.scalars[S_PILOT_SCALE0 + 0] = 1;
+            L.scalars[S_PILOT_SCALE0 + 1] = 2;
+            L.scalars[S_PILOT_SCALE0 + 2] = 4;
+            L.scalars[S_PILOT_SCALE0 + 3] = 8;
+            L.scalars[S_PILOT_LO] = 0;       // largest scale estimated not to fit
+            L.scalars[S_PILOT_HI] = 64;      // smallest scale estimated to fit
+        }
+        for (;;) {
+            __syncthreads();
+            const int np = L.scalars[S_PILOT_N];
+            if (np == 0) break;
+            if (wid * kPilotPerWave < n_pilot) {
+                for (int j = 0; j < np; j++) {
+                    const int s = L.scalars[S_PILOT_SCALE0 + j];
+                    const QuantK k = make_quant(lc.quant, s);
+                    int acc = 0;
+#pragma unroll
+                    for (int i = 0; i < kPilotPerWave; i++) acc += count_mb(cfp[i], k, lc, L.ac_len16) & 0xFF;
+                    const int t = wave::reduce_add(acc);
+                    if (lane == 0) atomicAdd(&L.scalars[S_PILOT_BITS0 + j], t);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int p_lo = L.scalars[S_PILOT_LO], p_hi = L.scalars[S_PILOT_HI];
+                for (int j = 0; j < np; j++) {
+                    const int s = L.scalars[S_PILOT_SCALE0 + j];
+                    const long long est = (long long)L.scalars[S_PILOT_BITS0 + j] * nmb / n_pilot + fixed_bits;
+                    if (est <= limit_bits) { if (s < p_hi) p_hi = s; }
+                    else if (s > p_lo) p_lo = s;
+                    L.scalars[S_PILOT_BITS0 + j] = 0;
+                }
+                if (p_hi < p_lo) p_hi = 64;     // non-monotone estimate: trust the failure, keep looking above it
+                int n = 0;
+                if (p_hi - p_lo > 1 && p_lo < 63) {
+                    if (p_hi == 64) {
+                        // nothing fits yet: geometric steps upwards
+                        const int c[4] = {p_lo + (p_lo >> 1), 2 * p_lo, 3 * p_lo, 4 * p_lo};
+                        int last = p_lo;
+                        for (int j = 0; j < 4; j++) {
+                            const int sc = c[j] > 63 ? 63 : c[j];
+                            if (sc > last) { L.scalars[S_PILOT_SCALE0 + n++] = sc; last = sc; }
+                        }
+                    } else {
+                        const int gap = p_hi - p_lo - 1;
+                        if (gap <= kPilotMax) {
+                            for (int j = 1; j <= gap; j++) L.scalars[S_PILOT_SCALE0 + n++] = p_lo + j;
+                        } else {
+                            for (int j = 1; j <= kPilotMax; j++) L.scalars[S_PILOT_SCALE0 + n++] = p_lo + gap * j / (kPilotMax + 1);
+                        }
                     }
                 }
-                const int cur = carry < thr ? lo : hi;            // last value after element i
-                int prev = __shfl_up(cur, 1, 64);
-                if (lane == 0) prev = carry;
-                int delta = (cur - prev) >> 2;                      // exact: both multiples of 4
-                if (CODEC == 2) {                                   // v3dc wrap (mdec.c:469-474)
-                    if (delta < -0x80) delta += 0x100;
-                    else if (delta > 0x80) delta -= 0x100;
-                }
-                int dlen;
-                uint32_t dcode;
-                dc_code<CODEC>(delta, wid == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
-                if (live) {
-                    L.dcv[idx] = (int16_t)delta;
-                    bits += dlen;
-                }
-                carry = __shfl(cur, 63, 64);
+                L.scalars[S_PILOT_N] = n;
+                L.scalars[S_PILOT_LO] = p_lo;
+                L.scalars[S_PILOT_HI] = p_hi;
+                if (n == 0) L.scalars[S_PILOT_GUESS] = p_hi > 63 ? 63 : p_hi;
             }
-            bits = wave::reduce_add(bits);
-            if (lane == 0) atomicAdd(&L.scalars[0], bits);
+        }
+        const int guess = L.scalars[S_PILOT_GUESS];
+
+        // ---- exact search (mdec_search.h): the state lives in LDS, thread 0 advances it between passes; every pass is
+        //      described by two scalars
+        MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
+        if (tid == 0) {
+            MdecSearch st;
+            mdec_search_init(st);
+            MdecPass np;
+            if (limit_bits < fixed_bits || bad_budget) {
+                np.done = 1; np.count_scale = 0; np.emit_scale = 0;
+            } else {
+                np = mdec_search_next(st, guess, limit_bits, fixed_bits);
+            }
+            *srch = st;
+            L.scalars[S_PASS_COUNT] = np.count_scale;
+            L.scalars[S_PASS_EMIT] = np.emit_scale;
+            L.scalars[S_DONE] = np.done;
+            L.scalars[S_RESULT] = st.best;
         }
         __syncthreads();
-        clk.mark(2);
 
-        // =====================================================================================
-        // (B) Rate control: first scale s with 8 + 2*ceil(bits(s)/16) <= max_size (mdec.c:663-723),
-        //     kScalesPerPass scales per pass over the slab
-        // =====================================================================================
-        int scale0 = 1;   // first scale of the current pass; scales 1..kScalesPerPass were counted in (A)
-        for (;;) {
-            if (scale0 > 1) {
-                fill_qtab(L.qtab, tid, lane, scale0);
+        int n_pass = 0;
+        while (!L.scalars[S_DONE]) {
+            const int count_scale = L.scalars[S_PASS_COUNT], emit_scale = L.scalars[S_PASS_EMIT];
+            n_pass++;
+            if (emit_scale && n_pass > 1) {
+                // a further emitting pass rebuilds the staging area
+                for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
+                if (tid == 0) { L.scalars[S_STG_NEXT] = 0; L.scalars[S_OVERFLOW] = 0; }
                 __syncthreads();
-                for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                    const int16_t* src = slab + ((unsigned)mbe * 384u + (unsigned)lane);
-                    const float2 k0 = L.qtab[lane], k1 = L.qtab[64 + lane], k2 = L.qtab[128 + lane], k3 = L.qtab[192 + lane];
-                    int acc01 = 0, acc23 = 0;
-                    const int live = live_scales(*(const int4*)L.pass_bits, limit_ac);
-                    // (kept as a rolled loop with a one-block prefetch: unrolling it costs registers that the
-                    // allocator takes from loop (A))
-                    int cnext = src[0];
-#pragma unroll 1
+            }
+            mc = mb_cursor(wid, nx);
+            next_mbe = mc.fx * ny + mc.fy;
+            if (wid < nmb) {
+                fetch(mc);
+                mb_advance<kWavesPerGroup>(mc, nx);
+            }
+            const QuantK kc = make_quant(lc.quant, count_scale ? count_scale : 1);
+            const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
+            int acc_cnt = 0;             // per lane: bits | deficit << 16 over this wavefront's macroblocks (count scale)
+            int acc_edef = 0;            // per lane: deficit over the emitted codes
+            int emit_bits = 0, nnz = 0;  // wave-uniform
+            const uint32_t lane_tag = (uint32_t)lane << 13;
+
+            int it = 0;
+            for (int m = wid; m < nmb; m += kWavesPerGroup, it++) {
+                if (WAVES == kWavesSmall) {
+                    if ((prio_bits >> (it & 7)) & 1u) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                const int mbe = next_mbe;
+                dct_mb(mbe, m + kWavesPerGroup < nmb, next_mbe);
+
+                if (count_scale) {
+                    const int a = count_mb(cf, kc, lc, L.ac_len16);
+                    acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
+                }
+
+                if (emit_scale) {
+                    // ---- 1. compaction.  At the accepted scale only a few of a block's 64 coefficients are non-zero, so the
+                    //      expensive part (VLC look-up, bit positions, LDS writes) runs on a COMPACTED list.
+                    //      Entry: [11:0] unclamped |level|, [12] sign, [18:13] scan position.  Lane 0 (scan position 0) is
+                    //      always kept: it marks the block's DC slot, so the list is exactly the macroblock's code sequence
+                    //      DC, AC..., DC, AC..., and the run before an AC coefficient is (its position - its predecessor's - 1).
+                    int count = 0;                             // wave-uniform
+#pragma unroll
                     for (int b = 0; b < 6; b++) {
-                        const int c = cnext;
-                        if (b < 5) cnext = src[(b + 1) * 64];
-                        count_block4(c, k0, k1, k2, k3, lc, L.ac_len, live, acc01, acc23);
+                        const int q = quant_mag(cf[b], ke);                    // <= 2048
+                        const uint64_t mk = wave::ballot(q != 0) | 1ull;
+                        if (q != 0 || lane == 0)
+                            clist[count + wave::popc_below(mk)] = (uint32_t)q | ((__float_as_uint(cf[b]) >> 19) & 0x1000u) | lane_tag;
+                        count += (int)__builtin_popcountll(mk);
                     }
-                    count_finish4(acc01, acc23, lane, &L.mb_bits[mbe * kScalesPerPass], L.pass_bits);
-                }
-                __syncthreads();
-            }
+                    nnz += count - 6;
+                    wave_sync();
 
-            if (tid == 0) {
-                const int fixed = L.scalars[0] + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
-                int chosen = 0;
-                for (int s = 0; s < kScalesPerPass && scale0 + s < 64; s++) {
-                    const int bits = L.pass_bits[s] + fixed;
-                    if (8 + 2 * ((bits + 15) >> 4) <= max_size) {
-                        chosen = scale0 + s;
-                        L.scalars[2] = s;
-                        L.scalars[4] = bits;
-                        break;
+                    // ---- 2. codes.  Each block's 2-bit end-of-block code "10" (mdec.c:501-503) travels as two extra leading
+                    //      bits of the NEXT block's DC code; the macroblock's last one is appended by stage_alloc().
+                    int kcarry = 0, bcarry = 0;
+                    // one chunk of <= 64 list entries: code and length per lane; advances the carries
+                    auto chunk = [&](int base, int& len, uint32_t& code, int& deficit) {
+                        const int i = base + lane;
+                        const bool live = i < count;
+                        const uint32_t e = live ? clist[i] : 0xFFFFFFFFu;      // dead lanes: scan position 63, never a DC slot
+                        const int k = (int)((e >> 13) & 63u);
+                        const bool neg = (e & 0x1000u) != 0;
+                        const bool is_dc = k == 0;
+                        int q = (int)(e & 0xFFFu);
+                        const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
+                        q = q > lim ? lim : q;
+                        const int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                        const bool is_ac = live && !is_dc;
+                        const int run = is_ac ? k - kprev - 1 : 0;
+                        const uint32_t entry = L.ac_code[lut_index(is_ac ? q : 0, run)];
+                        const int sl = neg ? -q : q;
+                        const uint32_t esc = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
+                        len = (int)(entry >> 24);
+                        code = len == BS_ESCAPE_BITS ? esc : ((entry & 0x1FFFFu) | (neg ? 1u : 0u));
+                        deficit = (int)((entry >> BS_LUT_DEFICIT_SHIFT) & 0xFu);
+                        // DC slots: block index = number of DC slots before this one in the macroblock's list
+                        const uint64_t dcmask = wave::ballot(is_dc);
+                        if (is_dc) {
+                            const int bi = bcarry + wave::popc_below(dcmask);
+                            dc_code<CODEC>((int)L.dcv[mbe * 6 + bi], bi >= 2, L.dc_plen, L.dc_prefix, len, code);
+                            if (bi > 0) {                               // carry the previous block's end-of-block code
+                                code |= 2u << len;
+                                len += 2;
+                            }
+                        }
+                        kcarry = __builtin_amdgcn_readlane(k, 63);
+                        bcarry += (int)__builtin_popcountll(dcmask);
+                    };
+                    // staging for a macroblock of `total` bits (+ the last block's end-of-block code): returns its bit position
+                    bool have_room = true;
+                    auto stage_alloc = [&](uint32_t total) -> uint32_t {
+                        const uint32_t mb_bits = total + 2u;
+                        const int ndw = (int)((mb_bits + 31u) >> 5);
+                        int off = 0;
+                        if (lane == 0) off = atomicAdd(&L.scalars[S_STG_NEXT], ndw);
+                        off = __builtin_amdgcn_readfirstlane(off);
+                        have_room = off + ndw <= job.stg_words;
+                        if (lane == 0) {
+                            if (!have_room) L.scalars[S_OVERFLOW] = 1;
+                            L.rec[mbe] = ((uint32_t)off & 0xFFFFu) | (mb_bits << 16);
+                            if (have_room) put_bits(L.stg, (uint32_t)off * 32u + total, 2, 2u);
+                        }
+                        emit_bits += (int)mb_bits;
+                        return (uint32_t)off * 32u;
+                    };
+                    if (count <= 64) {
+                        int len, deficit;
+                        uint32_t code;
+                        chunk(0, len, code, deficit);
+                        const int incl = wave::inclusive_scan_add(len);
+                        const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
+                        if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
+                        acc_edef += deficit;
+                    } else {
+                        // longer lists: add up the lengths first (the allocation needs the macroblock's total), then write
+                        int lsum = 0;
+                        for (int base = 0; base < count; base += 64) {
+                            int len, deficit;
+                            uint32_t code;
+                            chunk(base, len, code, deficit);
+                            lsum += len;
+                        }
+                        uint32_t pos = stage_alloc((uint32_t)wave::reduce_add(lsum));
+                        kcarry = 0;
+                        bcarry = 0;
+                        for (int base = 0; base < count; base += 64) {
+                            int len, deficit;
+                            uint32_t code;
+                            chunk(base, len, code, deficit);
+                            const int incl = wave::inclusive_scan_add(len);
+                            if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
+                            pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                            acc_edef += deficit;
+                        }
                     }
+                    wave_sync();   // the list is overwritten by the next macroblock's tiles
                 }
-                L.scalars[1] = chosen;
+            }
+            // ---- per-wavefront totals -> LDS
+            if (count_scale) {
+                const int tf = wave::reduce_add(acc_cnt & 0xFFFF), td = wave::reduce_add((int)((unsigned)acc_cnt >> 16));
+                if (lane == 0) { atomicAdd(&L.scalars[S_CNT_F], tf); atomicAdd(&L.scalars[S_CNT_D], td); }
+            }
+            if (emit_scale) {
+                const int td = wave::reduce_add(acc_edef);
+                if (lane == 0) {
+                    atomicAdd(&L.scalars[S_EMIT_BITS], emit_bits);
+                    atomicAdd(&L.scalars[S_EMIT_D], td);
+                    atomicAdd(&L.scalars[S_NNZ], nnz);
+                }
             }
             __syncthreads();
-            if (L.scalars[1] != 0 || scale0 + kScalesPerPass >= 64) break;
-            __syncthreads();
-            scale0 += kScalesPerPass;
-            if (tid < kScalesPerPass) L.pass_bits[tid] = 0;
+            if (tid == 0) {
+                MdecSearch st = *srch;
+                if (count_scale) {
+                    const int tb = L.scalars[S_CNT_F] + fixed_bits;
+                    mdec_search_note(st, count_scale, tb, tb - L.scalars[S_CNT_D], limit_bits);
+                }
+                if (emit_scale) {
+                    const int tb = L.scalars[S_EMIT_BITS] + 10;        // + end-of-frame code
+                    mdec_search_note(st, emit_scale, tb, tb - L.scalars[S_EMIT_D], limit_bits);
+                    st.staged = L.scalars[S_OVERFLOW] ? 0 : emit_scale;
+                    L.scalars[S_TOTAL_BITS] = tb;
+                }
+                const MdecPass np = mdec_search_next(st, guess, limit_bits, fixed_bits);
+                *srch = st;
+                L.scalars[S_PASS_COUNT] = np.count_scale;
+                L.scalars[S_PASS_EMIT] = np.emit_scale;
+                L.scalars[S_DONE] = np.done;
+                L.scalars[S_RESULT] = st.best;
+                if (!np.done) {
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0;
+                    if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
+                }
+            }
             __syncthreads();
         }
-        clk.mark(3);
+        n_done++;
+        if (job.stats && tid == 0) {
+            atomicAdd(&job.stats[0], 1ull);
+            atomicAdd(&job.stats[1], (unsigned long long)n_pass);
+            atomicAdd(&job.stats[2 + (n_pass > 5 ? 5 : n_pass)], 1ull);
+        }
 
-        const int scale = L.scalars[1];
+        const int scale = L.scalars[S_RESULT];
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
-        if (scale == 0 || bad_budget) {
+        if (scale >= 64 || bad_budget) {
             // nothing fits (the reference asserts, mdec.c:723): zero output, flag the result
             if (!bad_budget)
                 for (int i = tid; i < max_size; i += kThreads) outp[i] = 0;
@@ -658,7 +912,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             __syncthreads();
             continue;
         }
-        const int sidx = L.scalars[2];
 
         // =====================================================================================
         // Bit offsets of the macroblocks: exclusive scan in encode order (wave 0)
@@ -667,125 +920,42 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             uint32_t carry = 0;
             for (int base = 0; base < nmb; base += 64) {
                 const int mbe = base + lane;
-                int bits = 0;
-                if (mbe < nmb) {
-                    bits = L.mb_bits[mbe * kScalesPerPass + sidx] + 12;   // six end-of-block codes
-#pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        int dlen;
-                        uint32_t dcode;
-                        dc_code<CODEC>((int)L.dcv[mbe * 6 + b], b >= 2, L.dc_plen, L.dc_prefix, dlen, dcode);
-                        bits += dlen;
-                    }
-                }
+                const int bits = mbe < nmb ? (int)(L.rec[mbe] >> 16) : 0;
                 const int incl = wave::inclusive_scan_add(bits);
                 if (mbe < nmb) L.mb_off[mbe] = carry + (uint32_t)(incl - bits);
                 carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
             }
         }
         __syncthreads();
-        clk.mark(4);
 
         // =====================================================================================
-        // (C) Emit at the chosen scale.  At the accepted scale only a few of a block's 64 coefficients are
-        // non-zero, so the expensive part (VLC look-up, bit positions, LDS writes) runs on a COMPACTED list:
-        //   1. per block: quantise, ballot, and append {level, sign, scan position} of the non-zero lanes to a
-        //      per-wavefront list in LDS.  Lane 0 always appends the block's DC slot, so the list is exactly
-        //      the macroblock's code sequence: DC, AC..., DC, AC..., and the run before an AC coefficient is
-        //      simply (its position - its predecessor's position - 1);
-        //   2. per 64 list entries: look the codes up, prefix-sum their lengths, OR them into the frame image.
-        // Each block's 2-bit end-of-block code "10" (mdec.c:501-503) travels as two extra leading bits of the
-        // NEXT block's DC code; the frame's last one goes out with the end-of-frame code below.
+        // Merge: macroblock streams (dword-aligned in staging) -> their bit positions in the frame image.
+        // Output dword j of a macroblock at bit offset D = 32 w + sh receives  stg[j-1] << (32 - sh) | stg[j] >> sh
+        // (one v_alignbit); neighbouring macroblocks meet inside a dword, hence ds_or.
         // =====================================================================================
         {
-            const float inv1 = 1.0f / (float)(2 * lc.quant * scale), bias1 = 0.5f + 0.5f * inv1;
             uint32_t* stream = L.out + 2;                  // bitstream starts at byte 8 (mdec.c:686)
-            uint32_t* clist = (uint32_t*)tileT;            // the DCT tiles are idle now: 384 entries fit (kWaveTileBytes >= 1536)
-            const uint32_t lane_tag = (uint32_t)lane << 13;
-            int nnz = 0;
-            // the six coefficients of this lane are fetched one macroblock ahead (one memory latency per macroblock,
-            // hidden behind the previous macroblock's work)
-            int cn[6];
-            if (wid < nmb) {
-                const int16_t* src = slab + ((unsigned)wid * 384u + (unsigned)lane);
-#pragma unroll
-                for (int b = 0; b < 6; b++) cn[b] = src[b * 64];
-            }
             for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                int cc[6];
-#pragma unroll
-                for (int b = 0; b < 6; b++) cc[b] = cn[b];
-                if (mbe + kWavesPerGroup < nmb) {
-                    const int16_t* src = slab + ((unsigned)(mbe + kWavesPerGroup) * 384u + (unsigned)lane);
-#pragma unroll
-                    for (int b = 0; b < 6; b++) cn[b] = src[b * 64];
+                const uint32_t r = L.rec[mbe];
+                const int off = (int)(r & 0xFFFFu), ndw = (int)(((r >> 16) + 31u) >> 5);
+                const uint32_t D = L.mb_off[mbe];
+                const uint32_t w0 = D >> 5, sh = D & 31u;
+                for (int base = 0; base <= ndw; base += 64) {
+                    const int j = base + lane;
+                    const uint32_t cur = j < ndw ? L.stg[off + j] : 0u;
+                    const uint32_t prv = (j >= 1 && j <= ndw) ? L.stg[off + j - 1] : 0u;
+                    const uint32_t v = __builtin_amdgcn_alignbit(prv, cur, sh);
+                    if (v) atomicOr(&stream[w0 + (uint32_t)j], v);
                 }
-                // ---- 1. compaction.  Entry: [11:0] unclamped |level|, [12] sign, [18:13] scan position.
-                //      Lane 0 (scan position 0) is always kept: it marks the block's DC slot.
-                int count = 0;                             // wave-uniform
-#pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    const int c = cc[b];                       // scan position 0 holds 0 in the slab (the DC term lives in dcv)
-                    const int q = quant_mag((float)(2 * (c < 0 ? -c : c)), inv1, bias1);     // <= 2048
-                    const uint64_t m = wave::ballot(q != 0) | 1ull;
-                    if (q != 0 || lane == 0)
-                        clist[count + wave::popc_below(m)] = (uint32_t)q | (((uint32_t)c >> 19) & 0x1000u) | lane_tag;
-                    const int n = (int)__builtin_popcountll(m);
-                    count += n;
-                    nnz += n - 1;
-                }
-                wave_sync();
-
-                // ---- 2. codes
-                uint32_t pos = L.mb_off[mbe] - (mbe > 0 ? 2u : 0u);   // the previous macroblock's last end-of-block code starts here
-                int kcarry = 0, bcarry = 0;
-                for (int base = 0; base < count; base += 64) {
-                    const int i = base + lane;
-                    const bool live = i < count;
-                    const uint32_t e = live ? clist[i] : 0xFFFFFFFFu;      // dead lanes: scan position 63, never a DC slot
-                    const int k = (int)((e >> 13) & 63u);
-                    const bool neg = (e & 0x1000u) != 0;
-                    const bool is_dc = k == 0;
-                    int q = (int)(e & 0xFFFu);
-                    const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
-                    q = q > lim ? lim : q;
-                    const int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
-                    const bool is_ac = live && !is_dc;
-                    const int run = is_ac ? k - kprev - 1 : 0;
-                    const uint32_t entry = L.ac_code[lut_index(is_ac ? q : 0, run)];
-                    const int sl = neg ? -q : q;
-                    const uint32_t esc = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
-                    int len = (int)(entry >> 24);
-                    uint32_t code = len == BS_ESCAPE_BITS ? esc : ((entry & 0xFFFFFFu) | (neg ? 1u : 0u));
-                    // DC slots: block index = number of DC slots before this one in the macroblock's list
-                    const uint64_t dcmask = wave::ballot(is_dc);
-                    if (is_dc) {
-                        const int blk = bcarry + wave::popc_below(dcmask);
-                        dc_code<CODEC>((int)L.dcv[mbe * 6 + blk], blk >= 2, L.dc_plen, L.dc_prefix, len, code);
-                        if (blk > 0 || mbe > 0) {                   // carry the previous block's end-of-block code
-                            code |= 2u << len;
-                            len += 2;
-                        }
-                    }
-                    const int incl = wave::inclusive_scan_add(len);
-                    if (len) put_bits(stream, pos + (uint32_t)(incl - len), len, code);
-                    pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                    kcarry = __builtin_amdgcn_readlane(k, 63);
-                    bcarry += (int)__builtin_popcountll(dcmask);
-                }
-                wave_sync();   // the list is rewritten by the next macroblock
             }
-            if (lane == 0) atomicAdd(&L.scalars[3], nnz);
         }
         __syncthreads();
-        clk.mark(5);
 
         // ---- end-of-frame code, header, results (mdec.c:710-754)
-        const int total_bits = L.scalars[4];
+        const int total_bits = L.scalars[S_TOTAL_BITS];
         if (tid == 0) {
-            // last block's end-of-block code + end-of-frame code (mdec.c:647-651,710)
-            put_bits(L.out + 2, (uint32_t)(total_bits - 12), 12, (2u << 10) | (CODEC == 0 ? 0x1FFu : 0x3FFu));
-            int hwords = L.scalars[3] + 2 * nblk + 2;
+            put_bits(L.out + 2, (uint32_t)(total_bits - 10), 10, CODEC == 0 ? 0x1FFu : 0x3FFu);   // mdec.c:647-651,710
+            int hwords = L.scalars[S_NNZ] + 2 * nblk + 2;
             hwords = (hwords + 0x3F) & ~0x3F;
             const int blocks_used = (hwords + 1) >> 1;
             int bytes_used = 8 + 2 * ((total_bits + 15) >> 4);
@@ -818,24 +988,40 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
         }
         __syncthreads();
-        clk.mark(6);
+    }
+
+    if (job.stats && tid == 0 && blockIdx.x < PSXHIP_MDEC_TRACE_GROUPS) {
+        unsigned long long* t = job.stats + PSXHIP_MDEC_STATS + 4 * blockIdx.x;
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = (unsigned long long)n_done;
+        t[3] = (unsigned long long)hw_slot;
+    }
+    // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are
+    //      stream-ordered, see psxav_hip.h)
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&job.ticket[1], 1u) == gridDim.x - 1u) {
+            job.ticket[0] = 0u;
+            job.ticket[1] = 0u;
+            __threadfence();
+        }
     }
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// Host side of the kernel (called from psxhip_mdec.cpp through psxhip_internal.h)
+// Host side of the kernel (called from psxhip_api.cpp through psxhip_internal.h)
 // ---------------------------------------------------------------------------------------------
-extern "C" size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int large) {
-    return lds_bytes(nmb, out_words, large ? kWavesLarge : kWavesSmall);
+extern "C" size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int stg_words, int large) {
+    return lds_bytes(nmb, out_words, stg_words, large ? kWavesLarge : kWavesSmall);
 }
-extern "C" size_t psxhip_mdec_slab_bytes_per_group(int nmb) { return (size_t)nmb * 384 * sizeof(int16_t); }
 extern "C" int psxhip_mdec_threads_per_group(int large) { return (large ? kWavesLarge : kWavesSmall) * 64; }
 
 extern "C" hipError_t psxhip_mdec_upload_tables(void) {
     hipError_t e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ac_len), bs_ac_len_lut, sizeof(bs_ac_len_lut))) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ac_len16), bs_ac_len16_lut, sizeof(bs_ac_len16_lut))) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ac_code), bs_ac_code_lut, sizeof(bs_ac_code_lut))) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_zagzig), bs_zagzig, sizeof(bs_zagzig))) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_quant_zz), bs_quant_zz, sizeof(bs_quant_zz))) != hipSuccess) return e;
@@ -864,11 +1050,13 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.out = a->d_out;
     job.out_stride = a->out_stride;
     job.results = a->d_results;
-    job.coef_slab = a->d_coef_slab;
     job.out_words = a->out_words;
-    job.timing = a->d_timing;
+    job.stg_words = a->stg_words;
+    job.ticket = a->d_ticket;
+    job.stats = a->d_stats;
+    job.prio_pattern = a->prio_pattern;
     const int waves = a->large ? kWavesLarge : kWavesSmall;
-    const size_t lds = lds_bytes(job.nmb, job.out_words, waves);
+    const size_t lds = lds_bytes(job.nmb, job.out_words, job.stg_words, waves);
     const dim3 grid((unsigned)a->grid), block((unsigned)waves * 64u);
     hipStream_t st = (hipStream_t)a->stream;
 #define PSX_LAUNCH(CODEC)                                                                                             \

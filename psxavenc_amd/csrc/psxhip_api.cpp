@@ -55,7 +55,7 @@ extern "C" void psxhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* psxhip_last_error(void) { return g_err; }
-extern "C" const char* psxhip_version(void) { return "psxav_hip 0.1 (gfx950)"; }
+extern "C" const char* psxhip_version(void) { return "psxav_hip 0.2 (gfx950)"; }
 
 extern "C" int psxhip_device_count(void) {
     int n = 0;
@@ -69,12 +69,13 @@ int psxhip_ensure_device(int device) { return ensure_device(device); }
 
 struct psxhip_mdec_ctx {
     int device, codec, width, height, nmb;
-    int max_frame_size, out_words;
+    int max_frame_size, out_words, stg_words;
     int groups_max;            // persistent grid size: compute units x resident groups per CU
     int large;                 // 1: one 16-wavefront group per CU (two 12-wavefront groups do not fit the LDS)
     size_t lds_bytes;
-    int16_t* d_slab;
-    unsigned long long* d_timing;   // diagnostics (PSXHIP_MDEC_TIMING=1)
+    unsigned int* d_ticket;         // [2] frame hand-out counters (the kernel re-arms them when it ends)
+    unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
+    unsigned prio_pattern;
     // host-path staging
     hipStream_t stream;
     uint8_t* d_frames;
@@ -85,12 +86,67 @@ struct psxhip_mdec_ctx {
     size_t cap_out_stride;
 };
 
+namespace {
+// LDS working set of one frame for a geometry; *large = 1 when only the one-group-per-CU shape fits
+int mdec_geometry(int width, int height, int max_frame_size, size_t lds_cu, int* large, int* out_words, int* stg_words,
+                  size_t* lds_bytes) {
+    const int nmb = (width / 16) * (height / 16);
+    const int ow = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
+    const int sw = (max_frame_size + 3) / 4 + nmb + 2;
+    if (sw > 0xFFFF) return 0;                      // staging offsets are 16-bit
+    const int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow, sw, 0) > lds_cu;
+    const size_t need = psxhip_mdec_lds_bytes(nmb, ow, sw, lg);
+    if (large) *large = lg;
+    if (out_words) *out_words = ow;
+    if (stg_words) *stg_words = sw;
+    if (lds_bytes) *lds_bytes = need;
+    return need <= lds_cu;
+}
+bool mdec_args_ok(int codec, int width, int height, int max_frame_size) {
+    return !(codec < 0 || codec > 2 || width <= 0 || height <= 0 || (width % 16) || (height % 16) || width > 1024 ||
+             height > 1024 || max_frame_size < 8);
+}
+}  // namespace
+
+extern "C" int psxhip_mdec_query_geometry(int device, int codec, int width, int height, int max_frame_size,
+                                          psxhip_mdec_geometry_t* out) {
+    if (out) memset(out, 0, sizeof(*out));
+    if (!mdec_args_ok(codec, width, height, max_frame_size)) {
+        psxhip_set_error("bad MDEC geometry: codec %d, %dx%d, budget %d", codec, width, height, max_frame_size);
+        return PSXHIP_EINVAL;
+    }
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
+    const size_t lds_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+    int large = 0, ow = 0, sw = 0;
+    size_t need = 0;
+    const int fits = mdec_geometry(width, height, max_frame_size, lds_cu, &large, &ow, &sw, &need);
+    if (out) {
+        out->fits = fits;
+        out->groups_per_cu = fits ? (large ? 1 : 2) : 0;
+        out->wavefronts_per_group = psxhip_mdec_threads_per_group(large) / 64;
+        out->lds_bytes_per_group = (int64_t)need;
+        out->lds_bytes_per_cu = (int64_t)lds_cu;
+        out->frames_in_flight = fits ? prop.multiProcessorCount * (large ? 1 : 2) : 0;
+        // largest budget that still fits this frame size (the LDS need grows by 8 bytes per budget dword)
+        int lo = 8, hi = 1 << 20;
+        while (lo < hi) {
+            const int mid = lo + (hi - lo + 1) / 2;
+            if (mdec_geometry(width, height, mid, lds_cu, nullptr, nullptr, nullptr, nullptr)) lo = mid;
+            else hi = mid - 1;
+        }
+        out->max_frame_size_limit = mdec_geometry(width, height, lo, lds_cu, nullptr, nullptr, nullptr, nullptr) ? lo : 0;
+    }
+    return PSXHIP_OK;
+}
+
 extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec, int width, int height,
                                   int max_frame_size) {
     if (!out) return PSXHIP_EINVAL;
     *out = nullptr;
-    if (codec < 0 || codec > 2 || width <= 0 || height <= 0 || (width % 16) || (height % 16) || width > 1024 ||
-        height > 1024 || max_frame_size < 8) {
+    if (!mdec_args_ok(codec, width, height, max_frame_size)) {
         psxhip_set_error("bad MDEC geometry: codec %d, %dx%d, budget %d", codec, width, height, max_frame_size);
         return PSXHIP_EINVAL;
     }
@@ -109,29 +165,28 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     c->height = height;
     c->nmb = (width / 16) * (height / 16);
     c->max_frame_size = max_frame_size;
-    c->out_words = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
     const size_t lds_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     // shape: two 12-wavefront groups per CU when their LDS fits, else one 16-wavefront group
-    c->large = 2 * psxhip_mdec_lds_bytes(c->nmb, c->out_words, 0) > lds_cu;
-    c->lds_bytes = psxhip_mdec_lds_bytes(c->nmb, c->out_words, c->large);
-    if (c->lds_bytes > lds_cu) {
-        psxhip_set_error("frame budget %d with %d macroblocks needs %zu B of LDS (> %zu)", max_frame_size, c->nmb,
-                         c->lds_bytes, lds_cu);
+    if (!mdec_geometry(width, height, max_frame_size, lds_cu, &c->large, &c->out_words, &c->stg_words, &c->lds_bytes)) {
+        psxhip_set_error("frame budget %d with %d macroblocks needs %zu B of LDS (> %zu); see psxhip_mdec_query_geometry",
+                         max_frame_size, c->nmb, c->lds_bytes, lds_cu);
         return PSXHIP_EINVAL;
     }
     // opt the kernels into the whole LDS once (contexts with different geometries share the kernel attribute)
     HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
     c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
+    c->prio_pattern = 0xEE11u;
+    if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
 
-    const size_t slab = psxhip_mdec_slab_bytes_per_group(c->nmb) * (size_t)c->groups_max;
-    HIP_TRY(hipMalloc((void**)&c->d_slab, slab), PSXHIP_ENOMEM);
+    HIP_TRY(hipMalloc((void**)&c->d_ticket, 2 * sizeof(unsigned int)), PSXHIP_ENOMEM);
+    HIP_TRY(hipMemset(c->d_ticket, 0, 2 * sizeof(unsigned int)), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
-    if (const char* e = getenv("PSXHIP_MDEC_TIMING")) {
+    if (const char* e = getenv("PSXHIP_MDEC_STATS")) {
         if (atoi(e)) {
-            HIP_TRY(hipMalloc((void**)&c->d_timing, 16 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
-            HIP_TRY(hipMemset(c->d_timing, 0, 16 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
+            HIP_TRY(hipMalloc((void**)&c->d_stats, PSXHIP_MDEC_STATS_TOTAL * sizeof(unsigned long long)), PSXHIP_ENOMEM);
+            HIP_TRY(hipMemset(c->d_stats, 0, PSXHIP_MDEC_STATS_TOTAL * sizeof(unsigned long long)), PSXHIP_EDEVICE);
         }
     }
     guard.p = nullptr;                   // ownership passes to the caller
@@ -143,8 +198,8 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->d_slab) (void)hipFree(c->d_slab);
-    if (c->d_timing) (void)hipFree(c->d_timing);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_res) (void)hipFree(c->d_res);
@@ -187,12 +242,14 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.d_out = d_out;
     a.out_stride = out_stride;
     a.d_results = d_results;
-    a.d_coef_slab = c->d_slab;
     a.out_words = c->out_words;
+    a.stg_words = c->stg_words;
     a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
     a.large = c->large;
     a.stream = stream;
-    a.d_timing = c->d_timing;
+    a.d_ticket = c->d_ticket;
+    a.d_stats = c->d_stats;
+    a.prio_pattern = c->prio_pattern;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
@@ -266,14 +323,15 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
     return PSXHIP_OK;
 }
 
-extern "C" int psxhip_mdec_read_timing(psxhip_mdec_ctx_t* c, unsigned long long* out8, int reset) {
-    if (!c || !out8) return PSXHIP_EINVAL;
-    memset(out8, 0, 16 * sizeof(unsigned long long));
-    if (!c->d_timing) return PSXHIP_OK;
+extern "C" int psxhip_mdec_read_stats(psxhip_mdec_ctx_t* c, unsigned long long* out, int n, int reset) {
+    if (!c || !out || n < 0) return PSXHIP_EINVAL;
+    if (n > PSXHIP_MDEC_STATS_TOTAL) n = PSXHIP_MDEC_STATS_TOTAL;
+    memset(out, 0, (size_t)n * sizeof(unsigned long long));
+    if (!c->d_stats) return PSXHIP_OK;
     HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
     HIP_TRY(hipDeviceSynchronize(), PSXHIP_EDEVICE);
-    HIP_TRY(hipMemcpy(out8, c->d_timing, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
-    if (reset) HIP_TRY(hipMemset(c->d_timing, 0, 16 * sizeof(unsigned long long)), PSXHIP_EDEVICE);
+    HIP_TRY(hipMemcpy(out, c->d_stats, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
+    if (reset) HIP_TRY(hipMemset(c->d_stats, 0, PSXHIP_MDEC_STATS_TOTAL * sizeof(unsigned long long)), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
 

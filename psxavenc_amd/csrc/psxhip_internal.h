@@ -20,16 +20,17 @@ typedef struct {
 	uint8_t *d_out;
 	size_t out_stride;
 	psxhip_mdec_result_t *d_results;
-	int16_t *d_coef_slab;
-	int out_words;
+	int out_words;      /* LDS dwords of the frame image: (max_frame_size + 3) / 4 + 2 */
+	int stg_words;      /* LDS dwords of the macroblock staging area: (max_frame_size + 3) / 4 + nmb + 2 */
 	int grid;
-	int large;   /* 1: 16-wavefront groups, one per CU (large frames / budgets) */
+	int large;          /* 1: 16-wavefront groups, one per CU (large frames / budgets) */
 	void *stream;
-	unsigned long long *d_timing;
+	unsigned int *d_ticket;         /* [2] frame hand-out counters, zero between launches */
+	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
+	unsigned prio_pattern;          /* see FrameJob */
 } psxhip_mdec_launch_t;
 
-size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int large);
-size_t psxhip_mdec_slab_bytes_per_group(int nmb);
+size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int stg_words, int large);
 int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
