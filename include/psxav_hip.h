@@ -103,7 +103,10 @@ int psxhip_mdec_query_geometry(int device, int codec, int width, int height, int
 /* after those, 4 entries per workgroup (the first PSXHIP_MDEC_TRACE_GROUPS groups of the last launch): start and end
  * time (100 MHz wall clock), frames encoded, reserved */
 #define PSXHIP_MDEC_TRACE_GROUPS 1024
-#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS + 4 * PSXHIP_MDEC_TRACE_GROUPS)
+/* and then 8 per-phase time sums over all groups (100 MHz ticks of each group's first thread): 0 ticket/idle, 1 reset +
+ * DC pre-pass, 2 pilot, 3 passes over the frame, 4 offset scan + merge, 5 header + write-out */
+#define PSXHIP_MDEC_STATS_PHASE0 (PSXHIP_MDEC_STATS + 4 * PSXHIP_MDEC_TRACE_GROUPS)
+#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS_PHASE0 + 8)
 int psxhip_mdec_read_stats(psxhip_mdec_ctx_t *ctx, unsigned long long *out, int n, int reset);
 
 /* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */

@@ -64,6 +64,8 @@ struct FrameJob {
     psxhip_mdec_result_t* results;
     int out_words;           // LDS dwords reserved for one frame's output
     int stg_words;           // LDS dwords of the macroblock staging area
+    int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
+    int it_step;             // iteration visiting stride (coprime with trips), see PassCursor
     unsigned int* ticket;    // [2]: next frame to hand out, workgroups finished (self-resetting)
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
@@ -89,6 +91,12 @@ enum {
     S_PILOT_GUESS,
     S_PILOT_LO,
     S_PILOT_HI,
+    S_CK_DONE,          // checkpoint: macroblocks finished so far in this pass
+    S_ABORT,            // checkpoint verdict: 0 = carry on, else the new guess
+    S_ABORTS_LEFT,      // checkpoints still allowed for this frame
+    S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
+    S_HINT_BUDGET,      // ... and its budget
+    S_PAD1,
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -266,7 +274,7 @@ struct QuantK {
 __device__ __forceinline__ QuantK make_quant(int quant, int scale) {
     QuantK k;
     k.inv = 1.0f / (float)(quant * scale);      // IEEE division
-    k.bias = 0.5f + 0.25f * k.inv;
+    k.bias = __builtin_fmaf(0.25f, k.inv, 0.5f);
     return k;
 }
 __device__ __forceinline__ int quant_mag(float cf, const QuantK& k) {
@@ -330,6 +338,41 @@ __device__ __forceinline__ void dc_code(int v, int luma, const uint8_t* plen, co
 struct MbCursor {
     int fx, fy;
 };
+// Pass order: a pass is `trips` iterations; in iteration `it` the W wavefronts of a group take the W horizontally
+// adjacent macroblocks  row * W + w  (raster order, w = wavefront index) of "iteration row"  row = it * step mod trips.
+// The stride makes every prefix of a pass an even sample of the frame -- the quarter-pass checkpoint projects the
+// frame's bits from it -- while the wavefronts still share cache lines inside an iteration.
+struct PassCursor {
+    int m;          // raster index (>= nmb: nothing to do in this iteration)
+    int fx, fy;
+    int d_m, d_fx, d_fy;     // per-iteration increment  step * W
+    int w_m, w_fx, w_fy;     // wrap-around decrement    trips * W
+};
+__device__ __forceinline__ PassCursor pass_cursor(int wid, int waves, int trips, int step, int nx) {
+    PassCursor c;
+    c.m = wid;
+    c.fy = wid / nx;
+    c.fx = wid - c.fy * nx;
+    c.d_m = step * waves;
+    c.d_fy = c.d_m / nx;
+    c.d_fx = c.d_m - c.d_fy * nx;
+    c.w_m = trips * waves;
+    c.w_fy = c.w_m / nx;
+    c.w_fx = c.w_m - c.w_fy * nx;
+    return c;
+}
+__device__ __forceinline__ void pass_advance(PassCursor& c, int nx) {
+    c.m += c.d_m;
+    c.fx += c.d_fx;
+    c.fy += c.d_fy;
+    if (c.fx >= nx) { c.fx -= nx; c.fy++; }
+    if (c.m >= c.w_m) {
+        c.m -= c.w_m;
+        c.fx -= c.w_fx;
+        c.fy -= c.w_fy;
+        if (c.fx < 0) { c.fx += nx; c.fy--; }
+    }
+}
 __device__ __forceinline__ MbCursor mb_cursor(int raster_index, int nx) {
     MbCursor c;
     c.fy = raster_index / nx;
@@ -443,12 +486,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // first group on a SIMD holds the low slots); the groups take turns at raised priority, one macroblock at a time.
     const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
     const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
-    unsigned long long t_start = 0;
+    if (tid == 0) L.scalars[S_HINT] = 0;
+    unsigned long long t_start = 0, t_mark = 0;
+    auto mark = [&](int phase) {       // diagnostics: time since the previous mark goes to `phase`
+        if (job.stats && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + phase], now - t_mark);
+            t_mark = now;
+        }
+    };
     int n_done = 0;
-    if (job.stats) t_start = wall_clock64();
+    if (job.stats) t_start = t_mark = wall_clock64();
+    unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
+    if (tid == 0) next_ticket = atomicAdd(&job.ticket[0], 1u);
     for (;;) {
         // ---- next frame: tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
-        if (tid == 0) L.scalars[S_FRAME] = (int)atomicAdd(&job.ticket[0], 1u);
+        if (tid == 0) {
+            L.scalars[S_FRAME] = (int)next_ticket;
+            next_ticket = atomicAdd(&job.ticket[0], 1u);
+        }
         __syncthreads();
         const int f = L.scalars[S_FRAME];
         if (f >= job.n_frames) break;
@@ -463,10 +519,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // fits <=> 8 + 2*ceil(bits/16) <= max_size <=> bits <= 16 * floor((max_size - 8) / 2)   (mdec.c:321-333 in closed form)
         const int limit_bits = 16 * ((max_size - 8) >> 1);
 
+        mark(0);   // ticket + idle
         // ---- reset per-frame state
         for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME) L.scalars[tid] = 0;
+        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET) L.scalars[tid] = 0;
         __syncthreads();
 
         // =====================================================================================
@@ -475,26 +532,62 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // level-shifted samples (row pass 16 * row sum, column pass (16 * sum + 8) >> 4), so a pass of byte sums does it.
         // =====================================================================================
         if (CODEC != 0) {
-            MbCursor mc = mb_cursor(wid, nx);
-            for (int m = wid; m < nmb; m += kWavesPerGroup) {
-                const uint8_t* p = frame + (pl.lane_off + (uint32_t)mc.fy * pl.mb_row_step + (uint32_t)mc.fx * 16u);
-                const uint2 plo = *(const uint2*)p;
-                const uint2 phi = *(const uint2*)(p + pl.hi_off);
-                uint32_t a, b;
-                if (blk < 2) {
-                    const uint32_t m8 = blk == 0 ? 0x00FF00FFu : 0xFF00FF00u;
-                    a = __builtin_amdgcn_sad_u8(plo.x & m8, 0u, __builtin_amdgcn_sad_u8(plo.y & m8, 0u, 0u));
-                    b = __builtin_amdgcn_sad_u8(phi.x & m8, 0u, __builtin_amdgcn_sad_u8(phi.y & m8, 0u, 0u));
-                } else {
-                    a = __builtin_amdgcn_sad_u8(plo.x, 0u, 0u);
-                    b = __builtin_amdgcn_sad_u8(plo.y, 0u, 0u);
+            // Work item = 8 pixel rows x 128 bytes of one plane: lane = (16-byte chunk c = lane >> 3, row r = lane & 7), so a
+            // wavefront reads whole cache lines.  A luma chunk spans the two blocks of one macroblock column, a chroma chunk
+            // (8 interleaved Cr,Cb pairs) one Cr and one Cb block; the 8 row sums of a chunk sit in 8 adjacent lanes.
+            // Two items per iteration keep two loads in flight per lane.
+            {
+                const int cpr = W >> 4;                       // 16-byte chunks per row (both planes)
+                const int gpr = (cpr + 7) >> 3;               // chunk groups per row
+                const int luma_items = (H >> 3) * gpr, total_items = luma_items + (H >> 4) * gpr;
+                const int r = lane & 7, cl = lane >> 3;
+                auto item_addr = [&](int item, bool& chroma, int& R, int& c, bool& ok) -> const uint8_t* {
+                    chroma = item >= luma_items;
+                    const int it2 = chroma ? item - luma_items : item;
+                    R = it2 / gpr;
+                    c = (it2 - R * gpr) * 8 + cl;
+                    ok = item < total_items && c < cpr;
+                    return frame + ((chroma ? (uint32_t)W * (uint32_t)H : 0u) + (uint32_t)(R * 8 + r) * (uint32_t)W + (uint32_t)c * 16u);
+                };
+                auto item_sums = [&](const uint4& v, bool chroma, int R, int c, bool ok) {
+                    int s0, s1;
+                    if (!chroma) {
+                        s0 = (int)__builtin_amdgcn_sad_u8(v.x, 0u, __builtin_amdgcn_sad_u8(v.y, 0u, 0u));
+                        s1 = (int)__builtin_amdgcn_sad_u8(v.z, 0u, __builtin_amdgcn_sad_u8(v.w, 0u, 0u));
+                    } else {
+                        const uint32_t m8 = 0x00FF00FFu;      // NV21: Cr (V) at even bytes
+                        s0 = (int)__builtin_amdgcn_sad_u8(v.x & m8, 0u, __builtin_amdgcn_sad_u8(v.y & m8, 0u,
+                                  __builtin_amdgcn_sad_u8(v.z & m8, 0u, __builtin_amdgcn_sad_u8(v.w & m8, 0u, 0u))));
+                        s1 = (int)__builtin_amdgcn_sad_u8(v.x, 0u, __builtin_amdgcn_sad_u8(v.y, 0u,
+                                  __builtin_amdgcn_sad_u8(v.z, 0u, __builtin_amdgcn_sad_u8(v.w, 0u, 0u)))) - s0;
+                    }
+                    s0 += wave::dpp_or_zero<0xB1, 0xF, 0xF>(s0);    // quad_perm [1,0,3,2]
+                    s1 += wave::dpp_or_zero<0xB1, 0xF, 0xF>(s1);
+                    s0 += wave::dpp_or_zero<0x4E, 0xF, 0xF>(s0);    // quad_perm [2,3,0,1]
+                    s1 += wave::dpp_or_zero<0x4E, 0xF, 0xF>(s1);
+                    s0 += wave::dpp_or_zero<0x141, 0xF, 0xF>(s0);   // row_half_mirror: all 8 rows of the chunk
+                    s1 += wave::dpp_or_zero<0x141, 0xF, 0xF>(s1);
+                    if (r == 0 && ok) {
+                        const int mbe = chroma ? c * ny + R : c * ny + (R >> 1);
+                        const int b0 = chroma ? 0 : 2 + (R & 1) * 2;
+                        L.dcv[mbe * 6 + b0] = (int16_t)quant_dc(s0 - 64 * 128);
+                        L.dcv[mbe * 6 + b0 + 1] = (int16_t)quant_dc(s1 - 64 * 128);
+                    }
+                };
+                constexpr int kDcItems = 4;
+                for (int item = wid; item < total_items; item += kDcItems * kWavesPerGroup) {
+                    bool ch[kDcItems], ok[kDcItems];
+                    int R[kDcItems], c[kDcItems];
+                    uint4 v[kDcItems];
+#pragma unroll
+                    for (int u = 0; u < kDcItems; u++) {
+                        const uint8_t* pp = item_addr(item + u * kWavesPerGroup, ch[u], R[u], c[u], ok[u]);
+                        v[u] = make_uint4(0, 0, 0, 0);
+                        if (ok[u]) v[u] = *(const uint4*)pp;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kDcItems; u++) item_sums(v[u], ch[u], R[u], c[u], ok[u]);
                 }
-                int s = (int)(a + b);
-                s += wave::dpp_or_zero<0xB1, 0xF, 0xF>(s);    // quad_perm [1,0,3,2]
-                s += wave::dpp_or_zero<0x4E, 0xF, 0xF>(s);    // quad_perm [2,3,0,1]
-                s += wave::dpp_or_zero<0x141, 0xF, 0xF>(s);   // row_half_mirror: all 8 lanes of the block hold its sum
-                if (r8 == 0 && lane < 48) L.dcv[(mc.fx * ny + mc.fy) * 6 + blk] = (int16_t)quant_dc(s - 64 * 128);
-                mb_advance<kWavesPerGroup>(mc, nx);
             }
             __syncthreads();
             if (wid < 3) {
@@ -554,6 +647,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
             __syncthreads();
         }
+        mark(1);   // reset + DC pre-pass
         const int dc_bits = CODEC == 0 ? 10 * nblk : L.scalars[S_DC_BITS];
         const int fixed_bits = dc_bits + 2 * nblk + 10;   // DC codes + end-of-block codes + end-of-frame code
 
@@ -563,25 +657,20 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // macroblock only and leaves its coefficients in cf[]; the following pass picks them up (`resume`).
         // =====================================================================================
         float cf[6];            // this lane's coefficient of each block of the current macroblock, as float; lane 0 holds 0
-        MbCursor mc;
         uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
 
-        auto fetch = [&](const MbCursor& c) {
-            const uint8_t* p = frame + (pl.lane_off + (uint32_t)c.fy * pl.mb_row_step + (uint32_t)c.fx * 16u);
+        auto fetch = [&](int fx, int fy) {
+            const uint8_t* p = frame + (pl.lane_off + (uint32_t)fy * pl.mb_row_step + (uint32_t)fx * 16u);
             plo = *(const uint2*)p;
             phi = *(const uint2*)(p + pl.hi_off);
         };
         // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
-        auto dct_mb = [&](int mbe_cur, bool have_next, int& next_out) {
+        auto dct_mb = [&](int mbe_cur, bool have_next, int next_fx, int next_fy) {
             const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[0]);
             const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[1]);
             const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, pl.sel[2]);
             const uint32_t R1 = __builtin_amdgcn_perm(phi.x, plo.y, pl.sel[3]);
-            if (have_next) {               // mc points at the wavefront's next macroblock
-                fetch(mc);
-                next_out = mc.fx * ny + mc.fy;
-                mb_advance<kWavesPerGroup>(mc, nx);
-            }
+            if (have_next) fetch(next_fx, next_fy);
             int d[8];
             if (lane < 48) {
                 // -- row pass: lane = (block, row)
@@ -607,33 +696,48 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     *(int16_t*)(zb + a) = (int16_t)d[v];
                 }
             }
-            wave_sync();
-#pragma unroll
-            for (int b = 0; b < 6; b++) cf[b] = (float)(int)tileZ[b * kZStride + lane];
-            wave_sync();     // the tiles are free again (the code list aliases them)
+            wave_sync();     // tileZ holds the macroblock's coefficients, lane k <-> scan position k of each block
         };
 
         // ---- pilot: kPilotPerWave macroblocks per wavefront, spread evenly over the frame in raster order; their AC bits
         //      at a few scales, scaled up to the frame, predict the answer
+        // A group that has just encoded a frame with the same budget skips the pilot and starts from that frame's answer
+        // (consecutive tickets are neighbouring frames); the quarter-pass checkpoint catches the cases where it is off.
+        const int hint = L.scalars[S_HINT];
+        const bool trust_hint = hint >= 1 && hint <= 63 && L.scalars[S_HINT_BUDGET] == max_size;
+        if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
+        if (trust_hint) {
+            if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
+            __syncthreads();
+        } else {
         float cfp[kPilotPerWave][6];
-        int next_mbe = 0;            // the macroblock (encode order) whose pixels are in (plo, phi)
 #pragma unroll
         for (int i = 0; i < kPilotPerWave; i++) {
             const int pi = wid * kPilotPerWave + i;
             if (pi < n_pilot) {
-                mc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
-                fetch(mc);
-                dct_mb(mc.fx * ny + mc.fy, false, next_mbe);
+                const MbCursor pc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
+                fetch(pc.fx, pc.fy);
+                dct_mb(pc.fx * ny + pc.fy, false, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 6; b++) cf[b] = (float)(int)tileZ[b * kZStride + lane];
+                wave_sync();
             }
 #pragma unroll
             for (int b = 0; b < 6; b++) cfp[i][b] = pi < n_pilot ? cf[b] : 0.0f;
         }
         if (tid == 0) {
-            L.scalars[S_PILOT_N] = 4;
-            L.scalars[S_PILOT_SCALE0 + 0] = 1;
-            L.scalars[S_PILOT_SCALE0 + 1] = 2;
-            L.scalars[S_PILOT_SCALE0 + 2] = 4;
-            L.scalars[S_PILOT_SCALE0 + 3] = 8;
+            if (hint >= 2 && hint <= 63) {
+                // frames handled back to back by one group tend to need the same scale: two evaluations confirm it
+                L.scalars[S_PILOT_N] = 2;
+                L.scalars[S_PILOT_SCALE0 + 0] = hint - 1;
+                L.scalars[S_PILOT_SCALE0 + 1] = hint;
+            } else {
+                L.scalars[S_PILOT_N] = 4;
+                L.scalars[S_PILOT_SCALE0 + 0] = 1;
+                L.scalars[S_PILOT_SCALE0 + 1] = 2;
+                L.scalars[S_PILOT_SCALE0 + 2] = 4;
+                L.scalars[S_PILOT_SCALE0 + 3] = 8;
+            }
             L.scalars[S_PILOT_LO] = 0;       // largest scale estimated not to fit
             L.scalars[S_PILOT_HI] = 64;      // smallest scale estimated to fit
         }
@@ -688,7 +792,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (n == 0) L.scalars[S_PILOT_GUESS] = p_hi > 63 ? 63 : p_hi;
             }
         }
+        }
         const int guess = L.scalars[S_PILOT_GUESS];
+        mark(2);   // pilot
 
         // ---- exact search (mdec_search.h): the state lives in LDS, thread 0 advances it between passes; every pass is
         //      described by two scalars
@@ -720,67 +826,177 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (tid == 0) { L.scalars[S_STG_NEXT] = 0; L.scalars[S_OVERFLOW] = 0; }
                 __syncthreads();
             }
-            mc = mb_cursor(wid, nx);
-            next_mbe = mc.fx * ny + mc.fy;
-            if (wid < nmb) {
-                fetch(mc);
-                mb_advance<kWavesPerGroup>(mc, nx);
-            }
+            PassCursor cur = pass_cursor(wid, kWavesPerGroup, job.trips, job.it_step, nx);
+            bool cur_valid = cur.m < nmb;
+            if (cur_valid) fetch(cur.fx, cur.fy);
             const QuantK kc = make_quant(lc.quant, count_scale ? count_scale : 1);
             const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
             int acc_cnt = 0;             // per lane: bits | deficit << 16 over this wavefront's macroblocks (count scale)
             int acc_edef = 0;            // per lane: deficit over the emitted codes
-            int emit_bits = 0, nnz = 0;  // wave-uniform
-            const uint32_t lane_tag = (uint32_t)lane << 13;
+            int acc_codes = 0;           // per lane: codes emitted (AC codes + DC slots)
+            int emit_bits = 0, mb_done = 0;  // wave-uniform
+            // compaction threshold of this lane: smallest |n| that quantises to non-zero at the list's scale
+            const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
+            const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
+            const uint32_t lane_tag = (uint32_t)lane << 17;
+            // per-wavefront totals -> LDS (also used by the checkpoint: flushing resets the partial sums)
+            auto flush = [&]() {
+                if (count_scale) {
+                    const int tf = wave::reduce_add(acc_cnt & 0xFFFF), td = wave::reduce_add((int)((unsigned)acc_cnt >> 16));
+                    if (lane == 0) { atomicAdd(&L.scalars[S_CNT_F], tf); atomicAdd(&L.scalars[S_CNT_D], td); }
+                    acc_cnt = 0;
+                }
+                if (emit_scale) {
+                    const int td = wave::reduce_add(acc_edef), tc = wave::reduce_add(acc_codes);
+                    if (lane == 0) {
+                        atomicAdd(&L.scalars[S_EMIT_BITS], emit_bits);
+                        atomicAdd(&L.scalars[S_EMIT_D], td);
+                        atomicAdd(&L.scalars[S_NNZ], tc - 6 * mb_done);      // AC codes = all codes - the DC slots
+                    }
+                    acc_edef = 0; acc_codes = 0; emit_bits = 0;
+                }
+                if (lane == 0) atomicAdd(&L.scalars[S_CK_DONE], mb_done);
+                mb_done = 0;
+            };
+            // Checkpoint after a quarter of the pass: the macroblocks done so far are an even sample of the frame (PassCursor);
+            // if their bits, scaled up, say that this pass's scales cannot be the answer, stop and start over with a better guess
+            // instead of finding out at the end.  Projections only steer: nothing they say enters the search state.
+            const int check_it = (job.trips >= 8 && L.scalars[S_ABORTS_LEFT] > 0) ? job.trips >> 2 : -1;
+            bool aborted = false;
 
-            int it = 0;
-            for (int m = wid; m < nmb; m += kWavesPerGroup, it++) {
+            for (int it = 0; it < job.trips; it++) {
+                if (it == check_it) {
+                    flush();
+                    __syncthreads();
+                    if (tid == 0) {
+                        const int done = L.scalars[S_CK_DONE];
+                        long long pa = 0, pb = 0;
+                        if (count_scale) pa = (long long)L.scalars[S_CNT_F] * nmb / done + fixed_bits;
+                        if (emit_scale) pb = (long long)L.scalars[S_EMIT_BITS] * nmb / done + 10;
+                        const int g = mdec_search_checkpoint(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, 50);
+                        L.scalars[S_ABORT] = g;
+                        if (g) L.scalars[S_ABORTS_LEFT] = L.scalars[S_ABORTS_LEFT] - 1;
+                    }
+                    __syncthreads();
+                    if (L.scalars[S_ABORT]) { aborted = true; break; }
+                }
                 if (WAVES == kWavesSmall) {
                     if ((prio_bits >> (it & 7)) & 1u) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                const int mbe = next_mbe;
-                dct_mb(mbe, m + kWavesPerGroup < nmb, next_mbe);
-
-                if (count_scale) {
-                    const int a = count_mb(cf, kc, lc, L.ac_len16);
-                    acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
+                PassCursor nxt = cur;
+                pass_advance(nxt, nx);
+                const bool nxt_valid = it + 1 < job.trips && nxt.m < nmb;
+                const int mbe = cur.fx * ny + cur.fy;
+                const bool valid = cur_valid;
+                cur_valid = nxt_valid;
+                if (!valid) {
+                    if (nxt_valid) fetch(nxt.fx, nxt.fy);
+                    cur = nxt;
+                    continue;
                 }
+                dct_mb(mbe, nxt_valid, nxt.fx, nxt.fy);
+                cur = nxt;
+                mb_done++;
 
-                if (emit_scale) {
-                    // ---- 1. compaction.  At the accepted scale only a few of a block's 64 coefficients are non-zero, so the
-                    //      expensive part (VLC look-up, bit positions, LDS writes) runs on a COMPACTED list.
-                    //      Entry: [11:0] unclamped |level|, [12] sign, [18:13] scan position.  Lane 0 (scan position 0) is
-                    //      always kept: it marks the block's DC slot, so the list is exactly the macroblock's code sequence
-                    //      DC, AC..., DC, AC..., and the run before an AC coefficient is (its position - its predecessor's - 1).
+                int ci[6];       // this lane's coefficient (scan position = lane) of each block; lane 0 (the DC slot) holds 0
+#pragma unroll
+                for (int b = 0; b < 6; b++) ci[b] = (int)tileZ[b * kZStride + lane];
+                wave_sync();     // the tiles are free again (the code list aliases them)
+
+                if (!emit_scale) {
+                    // count-only pass (rare: closing a gap below a scale that is already staged)
+                    float cff[6];
+#pragma unroll
+                    for (int b = 0; b < 6; b++) cff[b] = (float)ci[b];
+                    const int a = count_mb(cff, kc, lc, L.ac_len16);
+                    acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
+                } else {
+                    // ---- 1. compaction.  At the scales that matter only a few of a block's 64 coefficients are non-zero, so
+                    //      everything expensive (VLC look-ups, bit positions, LDS writes) runs on a COMPACTED list, built once
+                    //      per macroblock at the pass's LOWER scale (a coefficient that is non-zero at a coarser scale is non-zero
+                    //      at every finer one): |n| quantises to non-zero  <=>  2|n| >= d  <=>  |n| >= ceil(d / 2).
+                    //      Entry: [15:0] |n|, [16] sign, [22:17] scan position.  Lane 0 (scan position 0) is always kept: it
+                    //      marks the block's DC slot, so the list is the macroblock's code sequence DC, AC..., DC, AC...
+                    //      A macroblock that is dense at the count scale (more than two chunks) is listed at the emit scale
+                    //      instead and counted in place (count_mb): walking a long list twice costs more than it saves.
+                    uint32_t mag[6];
+                    int n_low = 0;
+#pragma unroll
+                    for (int b = 0; b < 6; b++) {
+                        mag[b] = (uint32_t)(ci[b] < 0 ? -ci[b] : ci[b]);
+                        n_low += (int)__builtin_popcountll(wave::ballot(mag[b] >= thr_low));
+                    }
+                    const bool list_low = count_scale && n_low <= 122;     // the list holds the count scale's codes
+                    if (count_scale && !list_low) {
+                        float cff[6];
+#pragma unroll
+                        for (int b = 0; b < 6; b++) cff[b] = (float)ci[b];
+                        const int a = count_mb(cff, kc, lc, L.ac_len16);
+                        acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
+                    }
+                    const uint32_t list_thr = list_low ? thr_low : thr_emit;
                     int count = 0;                             // wave-uniform
 #pragma unroll
                     for (int b = 0; b < 6; b++) {
-                        const int q = quant_mag(cf[b], ke);                    // <= 2048
-                        const uint64_t mk = wave::ballot(q != 0) | 1ull;
-                        if (q != 0 || lane == 0)
-                            clist[count + wave::popc_below(mk)] = (uint32_t)q | ((__float_as_uint(cf[b]) >> 19) & 0x1000u) | lane_tag;
+                        const uint64_t mk = wave::ballot(mag[b] >= list_thr) | 1ull;
+                        if (mag[b] >= list_thr || lane == 0)
+                            clist[count + wave::popc_below(mk)] = mag[b] | ((uint32_t)ci[b] & 0x10000u) | lane_tag;
                         count += (int)__builtin_popcountll(mk);
                     }
-                    nnz += count - 6;
                     wave_sync();
 
-                    // ---- 2. codes.  Each block's 2-bit end-of-block code "10" (mdec.c:501-503) travels as two extra leading
-                    //      bits of the NEXT block's DC code; the macroblock's last one is appended by stage_alloc().
-                    int kcarry = 0, bcarry = 0;
-                    // one chunk of <= 64 list entries: code and length per lane; advances the carries
-                    auto chunk = [&](int base, int& len, uint32_t& code, int& deficit) {
+                    // ---- 2. one chunk of <= 64 list entries.
+                    //      Count scale (= the list's scale): every entry is a code; the run before an AC coefficient is
+                    //      (its position - its predecessor's - 1), one DPP shift.
+                    //      Emit scale (coarser): entries whose level drops to 0 fall out; the run is taken from the previous
+                    //      SURVIVING entry (ballot, count-leading-zeros below this lane, ds_bpermute).  DC slots always survive,
+                    //      so a run never crosses a block.  Each block's 2-bit end-of-block code "10" (mdec.c:501-503) travels
+                    //      as two extra leading bits of the NEXT block's DC code; the macroblock's last one is appended by
+                    //      stage_alloc().
+                    int kcarry_a = 0, kcarry_b = 0, bcarry = 0;
+                    auto chunk = [&](int base, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16) {
                         const int i = base + lane;
                         const bool live = i < count;
-                        const uint32_t e = live ? clist[i] : 0xFFFFFFFFu;      // dead lanes: scan position 63, never a DC slot
-                        const int k = (int)((e >> 13) & 63u);
-                        const bool neg = (e & 0x1000u) != 0;
+                        const uint32_t e = live ? clist[i] : (63u << 17);      // dead lanes: |n| = 0 at scan position 63
+                        const int k = (int)((e >> 17) & 63u);
+                        const bool neg = (e & 0x10000u) != 0;
                         const bool is_dc = k == 0;
-                        int q = (int)(e & 0xFFFu);
+                        const bool is_ac = live && !is_dc;
+                        const float magf = (float)(e & 0xFFFFu);
+                        const uint64_t dcmask = wave::ballot(is_dc);
+                        cnt16 = 0;
+                        int kprev;
+                        // the quantiser constants belong to the entry's scan position k, i.e. they sit in lane k's registers
+                        QuantK ek;
+                        ek.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, ke.inv)));
+                        ek.bias = __builtin_fmaf(0.25f, ek.inv, 0.5f);
+                        if (list_low) {
+                            const int ka = __builtin_amdgcn_update_dpp(kcarry_a, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                            if (do_count) {
+                                QuantK ck;
+                                ck.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, kc.inv)));
+                                ck.bias = __builtin_fmaf(0.25f, ck.inv, 0.5f);
+                                const int qa = quant_mag(magf, ck);
+                                cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
+                            }
+                            kcarry_a = __builtin_amdgcn_readlane(k, 63);
+                        }
+                        int q = quant_mag(magf, ek);                           // <= 2048
+                        if (list_low) {
+                            // previous surviving entry
+                            const uint64_t sm = wave::ballot(q != 0 || is_dc);
+                            const uint64_t below = sm & lc.below;
+                            const int ps = 63 - __clzll((long long)below);         // -1 when there is none in this chunk
+                            const int kp = __builtin_amdgcn_ds_bpermute(ps << 2, k);
+                            kprev = below ? kp : kcarry_b;
+                            if (sm) kcarry_b = __builtin_amdgcn_readlane(k, 63 - __builtin_clzll(sm));
+                        } else {
+                            kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
+                            kcarry_b = __builtin_amdgcn_readlane(k, 63);
+                        }
                         const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
                         q = q > lim ? lim : q;
-                        const int kprev = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
-                        const bool is_ac = live && !is_dc;
                         const int run = is_ac ? k - kprev - 1 : 0;
                         const uint32_t entry = L.ac_code[lut_index(is_ac ? q : 0, run)];
                         const int sl = neg ? -q : q;
@@ -789,7 +1005,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         code = len == BS_ESCAPE_BITS ? esc : ((entry & 0x1FFFFu) | (neg ? 1u : 0u));
                         deficit = (int)((entry >> BS_LUT_DEFICIT_SHIFT) & 0xFu);
                         // DC slots: block index = number of DC slots before this one in the macroblock's list
-                        const uint64_t dcmask = wave::ballot(is_dc);
                         if (is_dc) {
                             const int bi = bcarry + wave::popc_below(dcmask);
                             dc_code<CODEC>((int)L.dcv[mbe * 6 + bi], bi >= 2, L.dc_plen, L.dc_prefix, len, code);
@@ -798,7 +1013,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                                 len += 2;
                             }
                         }
-                        kcarry = __builtin_amdgcn_readlane(k, 63);
                         bcarry += (int)__builtin_popcountll(dcmask);
                     };
                     // staging for a macroblock of `total` bits (+ the last block's end-of-block code): returns its bit position
@@ -818,55 +1032,62 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         emit_bits += (int)mb_bits;
                         return (uint32_t)off * 32u;
                     };
+                    int mb_codes = 0;        // codes of the emit scale incl. the six DC slots (per lane partial)
                     if (count <= 64) {
-                        int len, deficit;
+                        int len, deficit, cnt16;
                         uint32_t code;
-                        chunk(0, len, code, deficit);
+                        chunk(0, list_low, len, code, deficit, cnt16);
                         const int incl = wave::inclusive_scan_add(len);
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
                         if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                         acc_edef += deficit;
+                        acc_cnt += (cnt16 & 0xFF) | ((cnt16 >> 8) << 16);
+                        mb_codes += len ? 1 : 0;
                     } else {
                         // longer lists: add up the lengths first (the allocation needs the macroblock's total), then write
                         int lsum = 0;
                         for (int base = 0; base < count; base += 64) {
-                            int len, deficit;
+                            int len, deficit, cnt16;
                             uint32_t code;
-                            chunk(base, len, code, deficit);
+                            chunk(base, list_low, len, code, deficit, cnt16);
                             lsum += len;
+                            acc_cnt += (cnt16 & 0xFF) | ((cnt16 >> 8) << 16);
                         }
                         uint32_t pos = stage_alloc((uint32_t)wave::reduce_add(lsum));
-                        kcarry = 0;
+                        kcarry_a = 0;
+                        kcarry_b = 0;
                         bcarry = 0;
                         for (int base = 0; base < count; base += 64) {
-                            int len, deficit;
+                            int len, deficit, cnt16;
                             uint32_t code;
-                            chunk(base, len, code, deficit);
+                            chunk(base, false, len, code, deficit, cnt16);
                             const int incl = wave::inclusive_scan_add(len);
                             if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                             acc_edef += deficit;
+                            mb_codes += len ? 1 : 0;
                         }
                     }
+                    acc_codes += mb_codes;
                     wave_sync();   // the list is overwritten by the next macroblock's tiles
                 }
             }
-            // ---- per-wavefront totals -> LDS
-            if (count_scale) {
-                const int tf = wave::reduce_add(acc_cnt & 0xFFFF), td = wave::reduce_add((int)((unsigned)acc_cnt >> 16));
-                if (lane == 0) { atomicAdd(&L.scalars[S_CNT_F], tf); atomicAdd(&L.scalars[S_CNT_D], td); }
-            }
-            if (emit_scale) {
-                const int td = wave::reduce_add(acc_edef);
-                if (lane == 0) {
-                    atomicAdd(&L.scalars[S_EMIT_BITS], emit_bits);
-                    atomicAdd(&L.scalars[S_EMIT_D], td);
-                    atomicAdd(&L.scalars[S_NNZ], nnz);
-                }
-            }
+            if (WAVES == kWavesSmall) __builtin_amdgcn_s_setprio(0);
+            if (!aborted) flush();
             __syncthreads();
             if (tid == 0) {
                 MdecSearch st = *srch;
+                if (aborted) {
+                    // the pass was cut short: no evaluation to record, the staging area holds a partial stream
+                    st.staged = 0;
+                    const MdecPass np = mdec_search_next(st, L.scalars[S_ABORT], limit_bits, fixed_bits);
+                    *srch = st;
+                    L.scalars[S_PASS_COUNT] = np.count_scale;
+                    L.scalars[S_PASS_EMIT] = np.emit_scale;
+                    L.scalars[S_DONE] = np.done;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0;
+                    L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
+                } else {
                 if (count_scale) {
                     const int tb = L.scalars[S_CNT_F] + fixed_bits;
                     mdec_search_note(st, count_scale, tb, tb - L.scalars[S_CNT_D], limit_bits);
@@ -884,13 +1105,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_DONE] = np.done;
                 L.scalars[S_RESULT] = st.best;
                 if (!np.done) {
-                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0;
                     if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
+                }
                 }
             }
             __syncthreads();
         }
         n_done++;
+        mark(3);   // passes
         if (job.stats && tid == 0) {
             atomicAdd(&job.stats[0], 1ull);
             atomicAdd(&job.stats[1], (unsigned long long)n_pass);
@@ -898,6 +1121,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
 
         const int scale = L.scalars[S_RESULT];
+        if (tid == 0) { L.scalars[S_HINT] = scale < 64 ? scale : 0; L.scalars[S_HINT_BUDGET] = max_size; }
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
         if (scale >= 64 || bad_budget) {
@@ -935,13 +1159,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // =====================================================================================
         {
             uint32_t* stream = L.out + 2;                  // bitstream starts at byte 8 (mdec.c:686)
-            for (int mbe = wid; mbe < nmb; mbe += kWavesPerGroup) {
-                const uint32_t r = L.rec[mbe];
-                const int off = (int)(r & 0xFFFFu), ndw = (int)(((r >> 16) + 31u) >> 5);
-                const uint32_t D = L.mb_off[mbe];
+            // four macroblocks per wavefront, 16 lanes each (a macroblock's stream is typically 6..16 dwords)
+            const int j0 = lane & 15;
+            for (int base = wid * 4; base < nmb; base += kWavesPerGroup * 4) {
+                const int mbe = base + (lane >> 4);
+                const bool valid = mbe < nmb;
+                const uint32_t r = valid ? L.rec[mbe] : 0u;
+                const int off = (int)(r & 0xFFFFu), ndw = valid ? (int)(((r >> 16) + 31u) >> 5) : -1;
+                const uint32_t D = valid ? L.mb_off[mbe] : 0u;
                 const uint32_t w0 = D >> 5, sh = D & 31u;
-                for (int base = 0; base <= ndw; base += 64) {
-                    const int j = base + lane;
+                for (int j = j0; wave::ballot(j <= ndw) != 0; j += 16) {
                     const uint32_t cur = j < ndw ? L.stg[off + j] : 0u;
                     const uint32_t prv = (j >= 1 && j <= ndw) ? L.stg[off + j - 1] : 0u;
                     const uint32_t v = __builtin_amdgcn_alignbit(prv, cur, sh);
@@ -951,6 +1178,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         __syncthreads();
 
+        mark(4);   // scan + merge
         // ---- end-of-frame code, header, results (mdec.c:710-754)
         const int total_bits = L.scalars[S_TOTAL_BITS];
         if (tid == 0) {
@@ -988,6 +1216,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
         }
         __syncthreads();
+        mark(5);   // header + write-out
     }
 
     if (job.stats && tid == 0 && blockIdx.x < PSXHIP_MDEC_TRACE_GROUPS) {
@@ -1035,7 +1264,25 @@ extern "C" hipError_t psxhip_mdec_upload_tables(void) {
     return hipSuccess;
 }
 
+// iteration visiting stride: coprime with `trips`, near 0.38 * trips, so that any prefix of a pass samples the frame evenly
+static int pick_it_step(int trips) {
+    if (trips <= 2) return 1;
+    const int want = (trips * 382 + 500) / 1000;
+    for (int d = 0; d < trips; d++) {
+        const int cand[2] = {want + d, want - d};
+        for (int i = 0; i < 2; i++) {
+            const int c = cand[i];
+            if (c < 1 || c >= trips) continue;
+            int x = c, y = trips;
+            while (y) { const int t = x % y; x = y; y = t; }
+            if (x == 1) return c;
+        }
+    }
+    return 1;
+}
+
 extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
+    const int waves_ = a->large ? kWavesLarge : kWavesSmall;
     FrameJob job;
     job.frames = a->d_frames;
     job.frame_stride = a->frame_stride;
@@ -1055,7 +1302,9 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.ticket = a->d_ticket;
     job.stats = a->d_stats;
     job.prio_pattern = a->prio_pattern;
-    const int waves = a->large ? kWavesLarge : kWavesSmall;
+    job.trips = (job.nmb + waves_ - 1) / waves_;
+    job.it_step = pick_it_step(job.trips);
+    const int waves = waves_;
     const size_t lds = lds_bytes(job.nmb, job.out_words, job.stg_words, waves);
     const dim3 grid((unsigned)a->grid), block((unsigned)waves * 64u);
     hipStream_t st = (hipStream_t)a->stream;

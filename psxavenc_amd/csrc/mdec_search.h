@@ -116,6 +116,31 @@ PSX_HD int mdec_search_predict(const MdecSearch& s, int guess, int room, int fix
     return p < 1 ? 1 : (p > 63 ? 63 : p);
 }
 
+// Quarter-pass checkpoint: `pa` / `pb` = the frame's total bits at the pass's count / emit scale as PROJECTED from the
+// macroblocks done so far (0 = that scale is not part of the pass).  Returns 0 to carry on, or a new guess when the
+// projection is clearly (margin_permille of the AC room) on the wrong side: the emit scale will not fit, or the count
+// scale fits already.  Projections never enter the search state -- they only steer.
+PSX_HD int mdec_search_checkpoint(const MdecSearch& s, int a, int pa, int b, int pb, int limit_bits, int fixed_bits,
+                                  int margin_permille) {
+    const int room = limit_bits - fixed_bits;
+    if (room <= 0) return 0;
+    const int margin = (int)((long long)room * margin_permille / 1000);
+    const bool too_low = b && pb > limit_bits + margin;       // the stream being built will not fit
+    const bool too_high = a && pa <= limit_bits - margin;     // the scale below it fits as well
+    if (!too_low && !too_high) return 0;
+    MdecSearch t = s;
+    if (a) mdec_search_note(t, a, pa, 0, limit_bits);
+    if (b) mdec_search_note(t, b, pb, 0, limit_bits);
+    int g = mdec_search_predict(t, b ? b : a, room, fixed_bits);
+    const int cur = b ? b : a + 1;
+    if (too_low && g <= cur) g = cur + 1;
+    if (too_high && g >= cur) g = cur - 1;
+    if (g <= s.lo) g = s.lo + 1;
+    if (g < 1) g = 1;
+    if (g > 63) g = 63;
+    return g == cur ? 0 : g;
+}
+
 // what to do next.  `guess` = predicted answer (used until something has been evaluated), `fixed_bits` = the
 // scale-independent part of the total (DC + end-of-block + end-of-frame codes)
 PSX_HD MdecPass mdec_search_next(const MdecSearch& s, int guess, int limit_bits, int fixed_bits) {

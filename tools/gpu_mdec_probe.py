@@ -43,12 +43,14 @@ def run(name, reps=20):
     print("%-8s %8.4f ms  %10.0f fps  passes/frame %.3f  hist(0,1,2,3,4,5+) %s  scales %s" % (
         name, ms, n / ms * 1e3, s[1] / max(1, s[0]), s[2:8], dict(zip(sc.tolist(), cnt.tolist()))), flush=True)
     if os.environ.get("PROBE_TRACE"):
-        NT = 8 + 4 * 1024
+        NT = 8 + 4 * 1024 + 8
         t = (C.c_ulonglong * NT)()
         enc.encode_frames_device(d, budget, d_out=out, d_results=res)
         torch.cuda.synchronize()
         L.psxhip_mdec_read_stats(enc._h, t, NT, 1)
-        a = np.array(list(t)[8:], dtype=np.int64).reshape(-1, 4)
+        ph = np.array(list(t)[8 + 4096:], dtype=np.float64)
+        print("   phase share %% (ticket/idle, reset+dc, pilot, passes, scan+merge, header+writeout): %s  total %.1f us/group" % (np.round(100 * ph[:6] / ph.sum(), 1).tolist(), ph.sum() / 100.0 / 512))
+        a = np.array(list(t)[8:8 + 4096], dtype=np.int64).reshape(-1, 4)
         a = a[a[:, 1] > 0]
         t0 = a[:, 0].min()
         st, en, nf = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]      # microseconds
