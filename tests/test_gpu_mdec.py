@@ -299,3 +299,55 @@ def test_out_of_range_device_budgets_are_contained(torch_cuda):
             assert rc == 0 and np.array_equal(out[k, :b], want[0]) and np.array_equal(res[k], want_res[0])
             assert (out[k, b:] == 0xAB).all()
     enc.close()
+
+
+def test_long_mixed_batch_exercises_hint_checkpoint_and_retry_paths(torch_cuda):
+    """thousands of small frames through one launch: every workgroup encodes many frames back to back (the previous
+    frame's answer seeds the next one), content and per-frame budgets change abruptly (wrong seeds -> checkpoint aborts,
+    extra passes), some frames are escape-heavy (the lower-bound proof is loose there).  Every byte against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    w, h, n = 192, 128, 2400                 # 96 macroblocks: 8 iterations per pass -> the checkpoint is active
+    npx = w * h
+    frames = np.zeros((n, npx * 3 // 2), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for k in range(n):
+        kind = (k // 7) % 5                  # runs of similar frames, then a cut
+        if kind == 0:
+            y = (xx * 255 // w + yy * 255 // h) // 2 + rng.integers(-3, 4, (h, w))
+        elif kind == 1:
+            a = int(rng.integers(1, 50))
+            y = 128 + rng.integers(-a, a + 1, (h, w))
+        elif kind == 2:
+            y = np.kron(rng.integers(0, 256, (h // 8, w // 8)), np.ones((8, 8), np.int64))
+        elif kind == 3:
+            y = np.full((h, w), int(rng.integers(0, 256)))
+            for _ in range(int(rng.integers(1, 40))):
+                y[int(rng.integers(0, h)), int(rng.integers(0, w))] = int(rng.integers(0, 256))
+        else:
+            y = ((xx // 3 + yy // 5) % 2) * int(rng.integers(20, 255)) + rng.integers(0, 3, (h, w))
+        frames[k, :npx] = np.clip(y, 0, 255).astype(np.uint8).ravel()
+        frames[k, npx:] = np.clip(128 + rng.integers(-20, 21, npx // 2), 0, 255).astype(np.uint8)
+    floor_bytes = 8 + 2 * ((96 * 6 * 12 + 10 + 15) // 16)
+    budgets = (floor_bytes + 64 + rng.integers(0, 9000, n)).astype(np.int32)
+    budgets[::11] = 6000                     # plus a recurring common budget
+    for codec in (0, 1, 2):
+        want, want_res, rc = O.mdec_encode(codec, w, h, frames, budgets, stride=int(budgets.max()))
+        if rc != 0:                          # drop frames that fit no scale (the oracle stops at the first)
+            keep = [k for k in range(n) if O.mdec_encode(codec, w, h, frames[k:k + 1], int(budgets[k]))[2] == 0]
+            fr, bd = frames[keep], budgets[keep]
+            want, want_res, rc = O.mdec_encode(codec, w, h, fr, bd, stride=int(budgets.max()))
+            assert rc == 0
+        else:
+            fr, bd = frames, budgets
+        enc = encoder(codec, w, h, int(budgets.max()))
+        d = torch.from_numpy(fr).to("cuda:0")
+        d_b = torch.from_numpy(bd).to("cuda:0")
+        d_out, d_res = enc.encode_frames_device(d, d_b)
+        torch.cuda.synchronize()
+        out, res = d_out.cpu().numpy()[:, :int(budgets.max())], d_res.cpu().numpy()
+        bad = [k for k in range(len(fr)) if not (np.array_equal(out[k, :bd[k]], want[k, :bd[k]]) and np.array_equal(res[k], want_res[k]))]
+        assert not bad, "codec %d: %d frames differ, first %d (budget %d, got scale %d want %d)" % (
+            codec, len(bad), bad[0], bd[bad[0]], res[bad[0], 0], want_res[bad[0], 0])
+        assert len(set(res[:, 0].tolist())) > 8         # the batch really spans many scales
+        enc.close()
