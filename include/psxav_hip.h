@@ -197,6 +197,52 @@ int psxhip_xa_encode_streams_host(int device, int format, int stereo, int freque
                                   int samples_per_stream, const int32_t *lbas, psxhip_adpcm_state_t *states,
                                   uint8_t *out, int64_t out_stride, int finalize);
 
+/* ---------------------------------------------------------------- STR / STRCD / STRV muxer -- */
+
+/* The reference's encode_file_str (psxavenc/filefmt.c:391-520) for inputs that are all there up front: every frame goes
+ * through ONE batched MDEC launch (the per-frame budgets are a closed-form function of the frame index,
+ * mdec.c:768-775), the audio is one XA stream encoded concurrently by the ADPCM kernels, and the host interleaves
+ * 2016-byte slices of the finished frames with the finished audio sectors on the reference's sector schedule
+ * ((sector % interleave) > 0 = video, filefmt.c:454-461).  Fields mirror args_t (psxavenc/args.h). */
+typedef struct {
+	int32_t format;             /* format_t: 6 = STR (2336-byte sectors), 7 = STRCD (2352), 9 = STRV */
+	int32_t video_codec;        /* bs_codec_t */
+	int32_t video_width, video_height;
+	int32_t str_fps_num, str_fps_den;
+	int32_t str_cd_speed;       /* 1 or 2 */
+	int32_t str_video_id;       /* 0x8001 */
+	int32_t trailing_audio;     /* FLAG_STR_TRAILING_AUDIO: audio sector last in each block instead of first */
+	int32_t audio_channels;     /* 0 = no audio stream (all sectors are video), 1, 2 */
+	int32_t audio_frequency;    /* 18900 / 37800 */
+	int32_t audio_bit_depth;    /* 4 / 8 */
+	int32_t audio_xa_file, audio_xa_channel;
+} psxhip_str_settings_t;
+
+typedef struct {
+	int32_t n_sectors;          /* the stream ends with the last frame's last sector */
+	int32_t n_video_sectors, n_audio_sectors;
+	int32_t sector_size;        /* 2336 or 2352 */
+	int32_t interleave;         /* sectors per block: 1 audio + (interleave - 1) video */
+	int32_t audio_samples_per_sector;   /* per channel */
+	int32_t max_frame_size;     /* largest per-frame budget */
+	int32_t reserved;
+	int64_t quant_scale_sum;    /* filled by psxhip_str_encode_host (mdec_encoder_state_t.quant_scale_sum) */
+} psxhip_str_plan_t;
+
+/* sector counts and sizes for n_frames frames (what a caller needs to size the output) */
+int psxhip_str_plan(const psxhip_str_settings_t *settings, int n_frames, psxhip_str_plan_t *plan);
+/* frame_max_size of frames first_frame .. first_frame + n_frames - 1 (so that any rank can budget its own frame range) */
+int psxhip_str_frame_budgets(const psxhip_str_settings_t *settings, int first_frame, int n_frames, int32_t *budgets);
+/* frames: n_frames NV21 frames back to back (w*h*3/2 bytes each); pcm: int16, interleaved L,R when stereo,
+ * pcm_samples_per_channel of them (shorter than the video: padded with silence).  out: plan.n_sectors * sector_size
+ * bytes.  Sector bytes the reference leaves unwritten (it muxes into an uninitialised stack buffer) are zero; the EOF
+ * submode bit is set on the last audio sector. */
+int psxhip_str_encode_host(int device, const psxhip_str_settings_t *settings, const uint8_t *frames, int n_frames,
+                           const int16_t *pcm, int64_t pcm_samples_per_channel, uint8_t *out, size_t out_size,
+                           psxhip_str_plan_t *plan);
+/* psxhip_str_encode_host keeps its MDEC context (device + pinned staging buffers) between calls; this releases it */
+void psxhip_str_release(void);
+
 /* ---------------------------------------------------------------- synthetic inputs --------- */
 
 /* Integer-only generators (same function as oracle/synth.c) so benchmarks can fill HBM directly. */

@@ -1,7 +1,7 @@
 /*
  * host_cdrom.c -- CD-ROM sector helpers of include/psxav_audio.h in host C (libpsxav/cdrom.c:45-111).
  * Used by callers that build video (mode 2 form 1) sectors around GPU-encoded frames; the audio sectors'
- * own headers and EDC are produced on the GPU (adpcm_kernels.hip).  Byte-wise table CRC instead of the
+ * own headers and EDC are produced on the GPU (adpcm_kernels.hip).  Table CRC (slicing-by-8) instead of the
  * reference's bit-serial loop (cdrom.c:30-41): same polynomial, same result.
  */
 #include <string.h>
@@ -11,22 +11,38 @@
 _Static_assert(sizeof(psx_cdrom_sector_mode1_t) == PSX_CDROM_SECTOR_SIZE, "mode 1 sector layout");
 _Static_assert(sizeof(psx_cdrom_sector_mode2_t) == PSX_CDROM_SECTOR_SIZE, "mode 2 sector layout");
 
-static uint32_t edc_table[256];
+/* slicing-by-8: edc_table[k][b] = CRC of byte b followed by k zero bytes; eight table look-ups per 8 input bytes */
+static uint32_t edc_table[8][256];
 static int edc_table_ready;
 
 static void edc_init(void) {
 	for (uint32_t i = 0; i < 256; i++) {
 		uint32_t v = i;
 		for (int k = 0; k < 8; k++) v = (v & 1u) ? (v >> 1) ^ 0xD8018001u : v >> 1;
-		edc_table[i] = v;
+		edc_table[0][i] = v;
 	}
-	edc_table_ready = 1;
+	for (uint32_t i = 0; i < 256; i++)
+		for (int k = 1; k < 8; k++) {
+			const uint32_t v = edc_table[k - 1][i];
+			edc_table[k][i] = (v >> 8) ^ edc_table[0][v & 0xFF];
+		}
+	__atomic_store_n(&edc_table_ready, 1, __ATOMIC_RELEASE);
 }
 
 static uint32_t edc(const uint8_t *p, int n) {
-	if (!edc_table_ready) edc_init();
+	if (!__atomic_load_n(&edc_table_ready, __ATOMIC_ACQUIRE)) edc_init();
 	uint32_t v = 0;
-	while (n--) v = (v >> 8) ^ edc_table[(v ^ *p++) & 0xFF];
+	while (n >= 8) {
+		uint32_t lo, hi;
+		memcpy(&lo, p, 4);
+		memcpy(&hi, p + 4, 4);
+		lo ^= v;                         /* little-endian host (x86-64 / the GPU box) */
+		v = edc_table[7][lo & 0xFF] ^ edc_table[6][(lo >> 8) & 0xFF] ^ edc_table[5][(lo >> 16) & 0xFF] ^ edc_table[4][lo >> 24] ^
+		    edc_table[3][hi & 0xFF] ^ edc_table[2][(hi >> 8) & 0xFF] ^ edc_table[1][(hi >> 16) & 0xFF] ^ edc_table[0][hi >> 24];
+		p += 8;
+		n -= 8;
+	}
+	while (n--) v = (v >> 8) ^ edc_table[0][(v ^ *p++) & 0xFF];
 	return v;
 }
 

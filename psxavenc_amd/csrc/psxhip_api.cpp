@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "psxhip_internal.h"
 
@@ -76,13 +78,16 @@ struct psxhip_mdec_ctx {
     unsigned int* d_ticket;         // [2] frame hand-out counters (the kernel re-arms them when it ends)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
-    // host-path staging
+    // host-path staging: two chunk-sized sets of device buffers and pinned host buffers (double buffering)
     hipStream_t stream;
-    uint8_t* d_frames;
-    uint8_t* d_out;
-    psxhip_mdec_result_t* d_res;
-    int32_t* d_sizes;
-    int cap_frames;
+    uint8_t* d_frames[2];
+    uint8_t* d_out[2];
+    psxhip_mdec_result_t* d_res[2];
+    int32_t* d_sizes[2];
+    uint8_t* h_in[2];                 // pinned
+    uint8_t* h_out[2];                // pinned: output rows, then the chunk's results
+    hipEvent_t chunk_done[2];
+    int cap_frames;                   // frames per chunk the buffers hold
     size_t cap_out_stride;
 };
 
@@ -194,16 +199,17 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     return PSXHIP_OK;
 }
 
+static void psxhip_mdec_free_staging(psxhip_mdec_ctx* c);
+
 extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_stats) (void)hipFree(c->d_stats);
-    if (c->d_frames) (void)hipFree(c->d_frames);
-    if (c->d_out) (void)hipFree(c->d_out);
-    if (c->d_res) (void)hipFree(c->d_res);
-    if (c->d_sizes) (void)hipFree(c->d_sizes);
+    psxhip_mdec_free_staging(c);
+    for (int b = 0; b < 2; b++)
+        if (c->chunk_done[b]) (void)hipEventDestroy(c->chunk_done[b]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
@@ -254,6 +260,42 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     return PSXHIP_OK;
 }
 
+static void psxhip_mdec_free_staging(psxhip_mdec_ctx* c) {
+    for (int b = 0; b < 2; b++) {
+        if (c->d_frames[b]) (void)hipFree(c->d_frames[b]);
+        if (c->d_out[b]) (void)hipFree(c->d_out[b]);
+        if (c->d_res[b]) (void)hipFree(c->d_res[b]);
+        if (c->d_sizes[b]) (void)hipFree(c->d_sizes[b]);
+        if (c->h_in[b]) (void)hipHostFree(c->h_in[b]);
+        if (c->h_out[b]) (void)hipHostFree(c->h_out[b]);
+        c->d_frames[b] = nullptr; c->d_out[b] = nullptr; c->d_res[b] = nullptr; c->d_sizes[b] = nullptr;
+        c->h_in[b] = nullptr; c->h_out[b] = nullptr;
+    }
+    c->cap_frames = 0;
+    c->cap_out_stride = 0;
+}
+
+namespace {
+// copy `bytes` with a few threads: one core moves ~10 GB/s, a pinned staging buffer can take several times that
+void parallel_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+    static const unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = bytes >= (8u << 20) ? (hw >= 16 ? 8u : (hw >= 4 ? hw / 2 : 1u)) : 1u;
+    if (t <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes + t - 1) / t + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (size_t o = per; o < bytes; o += per) th.emplace_back([=]() { memcpy(dst + o, src + o, (o + per <= bytes ? per : bytes - o)); });
+    memcpy(dst, src, per <= bytes ? per : bytes);
+    for (auto& x : th) x.join();
+}
+}  // namespace
+
+// Host buffers in, host buffers out.  The batch moves through in chunks on the context's stream: while the GPU works on
+// chunk k (H2D from a pinned buffer, kernel, D2H into a pinned buffer) the CPU stages chunk k+1 into the other pinned
+// buffer and hands chunk k-1's output to the caller -- pageable caller memory never waits on the DMA engine and the DMA
+// engine never reads pageable memory.
 extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_t* frames, int n_frames,
                                               const int32_t* frame_max_sizes, int uniform_max_size, uint8_t* out,
                                               size_t out_stride, psxhip_mdec_result_t* results) {
@@ -275,45 +317,74 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
             }
             if (frame_max_sizes[i] > max_size) max_size = frame_max_sizes[i];
         }
+    } else if (uniform_max_size < 8 || uniform_max_size > c->max_frame_size) {
+        psxhip_set_error("encode_frames_host: frame_max_size %d outside [8, %d]", uniform_max_size, c->max_frame_size);
+        return PSXHIP_EINVAL;
     }
     if ((size_t)max_size > out_stride) {
         psxhip_set_error("encode_frames_host: out_stride %zu smaller than the largest budget %d", out_stride, max_size);
         return PSXHIP_EINVAL;
     }
     const size_t dstride = ((size_t)max_size + 3) & ~(size_t)3;
-    if (n_frames > c->cap_frames || dstride > c->cap_out_stride) {
-        const int cap = n_frames > c->cap_frames ? n_frames : c->cap_frames;
+    // chunk: enough frames to fill the GPU a few times over, small enough that staging stays cache- and latency-friendly
+    int chunk = c->groups_max * 2;
+    if (chunk > n_frames) chunk = n_frames;
+    if (chunk > c->cap_frames || dstride > c->cap_out_stride) {
+        const int cap = chunk > c->cap_frames ? chunk : c->cap_frames;
         const size_t os = dstride > c->cap_out_stride ? dstride : c->cap_out_stride;
-        if (c->d_frames) (void)hipFree(c->d_frames);
-        if (c->d_out) (void)hipFree(c->d_out);
-        if (c->d_res) (void)hipFree(c->d_res);
-        if (c->d_sizes) (void)hipFree(c->d_sizes);
-        c->d_frames = nullptr; c->d_out = nullptr; c->d_res = nullptr; c->d_sizes = nullptr;
-        c->cap_frames = 0;
-        c->cap_out_stride = 0;
-        HIP_TRY(hipMalloc((void**)&c->d_frames, fsz * cap), PSXHIP_ENOMEM);
-        HIP_TRY(hipMalloc((void**)&c->d_out, os * cap), PSXHIP_ENOMEM);
-        HIP_TRY(hipMalloc((void**)&c->d_res, sizeof(psxhip_mdec_result_t) * cap), PSXHIP_ENOMEM);
-        HIP_TRY(hipMalloc((void**)&c->d_sizes, sizeof(int32_t) * cap), PSXHIP_ENOMEM);
+        psxhip_mdec_free_staging(c);
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipMalloc((void**)&c->d_frames[b], fsz * cap), PSXHIP_ENOMEM);
+            HIP_TRY(hipMalloc((void**)&c->d_out[b], os * cap), PSXHIP_ENOMEM);
+            HIP_TRY(hipMalloc((void**)&c->d_res[b], sizeof(psxhip_mdec_result_t) * cap), PSXHIP_ENOMEM);
+            HIP_TRY(hipMalloc((void**)&c->d_sizes[b], sizeof(int32_t) * cap), PSXHIP_ENOMEM);
+            HIP_TRY(hipHostMalloc((void**)&c->h_in[b], fsz * cap + sizeof(int32_t) * cap, hipHostMallocDefault), PSXHIP_ENOMEM);
+            HIP_TRY(hipHostMalloc((void**)&c->h_out[b], os * cap + sizeof(psxhip_mdec_result_t) * cap, hipHostMallocDefault), PSXHIP_ENOMEM);
+            if (!c->chunk_done[b]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
+        }
         c->cap_frames = cap;
         c->cap_out_stride = os;
     }
-    // rows are copied back max_size wide; bytes past a frame's own (smaller) budget read as zero
-    if (frame_max_sizes)
-        HIP_TRY(hipMemsetAsync(c->d_out, 0, c->cap_out_stride * (size_t)n_frames, c->stream), PSXHIP_EDEVICE);
-    HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fsz * n_frames, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
-    if (frame_max_sizes)
-        HIP_TRY(hipMemcpyAsync(c->d_sizes, frame_max_sizes, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice, c->stream),
-                PSXHIP_EDEVICE);
-    int rc = psxhip_mdec_encode_frames_device(c, c->d_frames, fsz, n_frames, frame_max_sizes ? c->d_sizes : nullptr,
-                                              uniform_max_size, c->d_out, c->cap_out_stride, c->d_res, c->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(out, out_stride, c->d_out, c->cap_out_stride, (size_t)max_size, (size_t)n_frames,
-                             hipMemcpyDeviceToHost, c->stream),
-            PSXHIP_EDEVICE);
-    HIP_TRY(hipMemcpyAsync(results, c->d_res, sizeof(psxhip_mdec_result_t) * n_frames, hipMemcpyDeviceToHost, c->stream),
-            PSXHIP_EDEVICE);
-    HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+    const size_t os = c->cap_out_stride;
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    // hand a finished chunk to the caller
+    auto deliver = [&](int k) {
+        const int b = k & 1, first = k * chunk, cnt = (first + chunk <= n_frames) ? chunk : n_frames - first;
+        const uint8_t* src = c->h_out[b];
+        if (os == out_stride) {
+            parallel_copy(out + (size_t)first * out_stride, src, os * (size_t)cnt);
+        } else {
+            for (int i = 0; i < cnt; i++) memcpy(out + (size_t)(first + i) * out_stride, src + (size_t)i * os, (size_t)max_size);
+        }
+        memcpy(results + first, src + os * (size_t)c->cap_frames, sizeof(psxhip_mdec_result_t) * (size_t)cnt);
+    };
+    for (int k = 0; k < n_chunks; k++) {
+        const int b = k & 1, first = k * chunk, cnt = (first + chunk <= n_frames) ? chunk : n_frames - first;
+        if (k >= 2) {
+            HIP_TRY(hipEventSynchronize(c->chunk_done[b]), PSXHIP_EDEVICE);      // chunk k-2 left the GPU: its buffers are free
+            deliver(k - 2);
+        }
+        parallel_copy(c->h_in[b], frames + (size_t)first * fsz, fsz * (size_t)cnt);
+        HIP_TRY(hipMemcpyAsync(c->d_frames[b], c->h_in[b], fsz * (size_t)cnt, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
+        if (frame_max_sizes) {
+            int32_t* hs = (int32_t*)(c->h_in[b] + fsz * (size_t)c->cap_frames);
+            memcpy(hs, frame_max_sizes + first, sizeof(int32_t) * (size_t)cnt);
+            HIP_TRY(hipMemcpyAsync(c->d_sizes[b], hs, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
+            // rows are handed back max_size wide; bytes past a frame's own (smaller) budget read as zero
+            HIP_TRY(hipMemsetAsync(c->d_out[b], 0, os * (size_t)cnt, c->stream), PSXHIP_EDEVICE);
+        }
+        int rc = psxhip_mdec_encode_frames_device(c, c->d_frames[b], fsz, cnt, frame_max_sizes ? c->d_sizes[b] : nullptr,
+                                                  uniform_max_size, c->d_out[b], os, c->d_res[b], c->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_out[b], c->d_out[b], os * (size_t)cnt, hipMemcpyDeviceToHost, c->stream), PSXHIP_EDEVICE);
+        HIP_TRY(hipMemcpyAsync(c->h_out[b] + os * (size_t)c->cap_frames, c->d_res[b], sizeof(psxhip_mdec_result_t) * (size_t)cnt,
+                               hipMemcpyDeviceToHost, c->stream), PSXHIP_EDEVICE);
+        HIP_TRY(hipEventRecord(c->chunk_done[b], c->stream), PSXHIP_EDEVICE);
+    }
+    for (int k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; k++) {
+        HIP_TRY(hipEventSynchronize(c->chunk_done[k & 1]), PSXHIP_EDEVICE);
+        deliver(k);
+    }
     for (int i = 0; i < n_frames; i++)
         if (results[i].quant_scale >= 64) {
             psxhip_set_error("frame %d does not fit %d bytes at any quant scale", i,

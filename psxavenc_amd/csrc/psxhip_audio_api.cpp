@@ -62,7 +62,10 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
 
-    const size_t per = (size_t)samples_per_stream * pitch;          // elements copied per stream
+    const size_t per = (size_t)samples_per_stream * pitch;          // device row stride (elements)
+    // the reference reads samples[i * pitch] for i < n (adpcm.c:65,110): only (n - 1) * pitch + 1 elements of a
+    // stream are the caller's to read -- `samples + channel` with pitch = channels ends before a full n * pitch
+    const size_t readable = samples_per_stream ? (size_t)(samples_per_stream - 1) * pitch + 1 : 0;
     std::vector<psxhip_adpcm_chain_t> chains(n_streams);
     std::vector<int32_t> base(n_streams);
     for (int i = 0; i < n_streams; i++) {
@@ -81,8 +84,9 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     HIP_TRY(d_u.alloc((size_t)n_streams * n_units * PSXHIP_ADPCM_RECORD_BYTES), PSXHIP_ENOMEM);
     HIP_TRY(d_o.alloc((size_t)n_streams * bytes), PSXHIP_ENOMEM);
     hipStream_t st = nullptr;
+    HIP_TRY(hipMemsetAsync(d_s.p, 0, per * n_streams * sizeof(int16_t), st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpy2DAsync(d_s.p, per * sizeof(int16_t), samples, (size_t)stream_stride * sizeof(int16_t),
-                             per * sizeof(int16_t), (size_t)n_streams, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
+                             readable * sizeof(int16_t), (size_t)n_streams, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_c.p, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_st.p, states, n_streams * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);

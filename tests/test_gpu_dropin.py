@@ -212,3 +212,98 @@ def test_c_example_program_builds_runs_and_matches_oracle(tmp_path):
         c[:, 1::2] = (160 - ys * 64 // (h // 2)).astype(np.uint8)[:, None]
     want, _, rc = O.mdec_encode(1, w, h, frames, 8192)
     assert rc == 0 and np.array_equal(data, want)
+
+
+def _oracle_str_stream(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm, channels=2, freq=37800, bits=4,
+                       trailing=False, n_sectors=None):
+    """the sector loop of encode_file_str (filefmt.c:450-503) over the oracle's restatements, sector buffers zeroed
+    first; ends with the last frame's last sector, EOF on the last audio sector."""
+    n_frames = frames.shape[0]
+    ofmt = {6: O.FMT_STR, 7: O.FMT_STRCD, 9: O.FMT_STRV}[fmt]
+    oxs = O.XaSettings(1 if fmt == 7 else 0, 1 if channels == 2 else 0, freq, bits, 1, 0)
+    ssz = 2352 if fmt == 7 else 2336
+    if channels:
+        interleave = O.lib().orc_xa_sector_interleave(oxs) * cd_speed
+        sps = O.lib().orc_xa_samples_per_sector(oxs)
+        vspb = interleave - 1
+    else:
+        interleave, sps, vspb = 1, 0, 1
+    base, den = 75 * cd_speed * vspb * fps_den, interleave * fps_num
+    cap = 2016 * -(-base // den)
+    ofo = np.zeros(cap, np.uint8)
+    ost = O.StrState(0, 0, 0, base, 0, den, 0, 0, ofo.ctypes.data)
+    oastate = O.State()
+    out = []
+    audio_at = []
+    frame_cursor, audio_cursor, sector_count = 0, 0, 0
+    while True:
+        if frame_cursor >= n_frames and ost.frame_data_offset >= ost.frame_max_size:
+            break                        # the for-condition of filefmt.c:450 with all input consumed
+        if channels == 0:
+            is_video = True
+        elif trailing:
+            is_video = (sector_count % interleave) < vspb
+        else:
+            is_video = (sector_count % interleave) > 0
+        want = np.zeros(2352, np.uint8)
+        if is_video:
+            if fmt == 7:
+                O.lib().orc_cdrom_init_sector(O.ptr(want, O.u8p), sector_count, 1)
+                want[16:20] = [1, 0, 0x08 | 0x40, 0]
+                want[20:24] = want[16:20]
+            elif fmt == 6:
+                want[0:4] = [1, 0, 0x08 | 0x40, 0]
+                want[4:8] = want[0:4]
+            fr = frames[min(frame_cursor, n_frames - 1)]
+            used = O.lib().orc_mdec_encode_sector_str(C.byref(ost), codec, w, h, ofmt, 0x8001, O.ptr(fr, O.u8p), O.ptr(want, O.u8p))
+            assert used >= 0
+            O.lib().orc_cdrom_calculate_checksums(O.ptr(want, O.u8p), 1)
+            frame_cursor += used
+        else:
+            chunk = pcm[channels * audio_cursor:]
+            w_, oastate = O.xa_encode(oxs, chunk, sps, lba=sector_count, state=oastate)
+            want[:ssz] = w_[:ssz]
+            audio_cursor += sps
+            audio_at.append(len(out))
+        out.append(want[:ssz].copy())
+        sector_count += 1
+    # the muxed stream ends with the last frame's last sector; the last audio sector carries EOF (adpcm.c:334-340)
+    while audio_at and audio_at[-1] >= len(out):
+        audio_at.pop()
+    stream = np.stack(out)
+    if audio_at:
+        k = audio_at[-1]
+        sub = 0x12 if fmt == 7 else 0x02
+        stream[k, sub] |= 0x80
+        stream[k, sub + 4] |= 0x80
+    return stream, ost.quant_scale_sum
+
+
+@pytest.mark.parametrize("fmt,codec,w,h,n_frames,channels", [(7, 0, 320, 240, 160, 2), (6, 1, 160, 112, 40, 1), (9, 2, 96, 64, 30, 0)])
+def test_batched_str_mux_whole_stream_vs_oracle_loop(fmt, codec, w, h, n_frames, channels):
+    """psxhip_str_encode_host (product code: one batched MDEC launch + one XA stream + host interleave) against the
+    reference's sector-by-sector loop restated over the oracle, whole stream, for config 'strcd v2' (160 frames) and the
+    other two STR flavours."""
+    from psxavenc_amd import strmux
+    s = strmux.settings(fmt=fmt, codec=codec, width=w, height=h, channels=channels, frequency=37800, bits=4)
+    frames = O.synth_frames(w, h, n_frames, seed=21, amp=6)
+    p = strmux.plan(s, n_frames)
+    if channels:
+        n = p.n_audio_sectors * p.audio_samples_per_sector
+        pcm = np.zeros((n + 4032) * channels, np.int16)
+        for c in range(channels):
+            pcm[c:channels * n:channels] = O.synth_pcm(9, c, 0, n, 0)
+    else:
+        pcm = np.zeros(0, np.int16)
+    got, p2 = strmux.encode(s, frames, pcm)
+    want, qsum = _oracle_str_stream(fmt, codec, w, h, 15, 1, 2, frames, pcm, channels=channels)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
+    assert p2.quant_scale_sum == qsum
+    if fmt == 7:
+        b = strmux.frame_budgets(s, 0, 5).tolist()
+        assert b == [16128, 18144, 18144, 18144, 16128]
+        import hashlib
+        # pinned: 160 frames of config 'strcd v2' (seed 21, noise +-6) = 1600 sectors
+        assert hashlib.sha256(got.tobytes()).hexdigest() == "f2eb7256f1a0e02d681d030651011cfeb9d0ee7cf2c59687a68f579d2b697add"

@@ -19,3 +19,9 @@ t = time.perf_counter()
 for _ in range(5): enc.encode_frames_host(fr, budget)
 dt = (time.perf_counter() - t) / 5
 print("encode_frames_host (1000 frames per call, pageable host buffers, H2D+kernel+D2H): %.0f frames/s (%.2f ms per call)" % (1000 / dt, dt * 1e3))
+fr8 = np.concatenate([fr] * 8)
+out8 = enc.encode_frames_host(fr8, budget)
+t = time.perf_counter()
+for _ in range(3): enc.encode_frames_host(fr8, budget)
+dt = (time.perf_counter() - t) / 3
+print("encode_frames_host (8000 frames per call, pageable host buffers, chunked double-buffered pipeline): %.0f frames/s (%.2f ms per call)" % (8000 / dt, dt * 1e3))
