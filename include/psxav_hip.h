@@ -243,6 +243,29 @@ int psxhip_str_encode_host(int device, const psxhip_str_settings_t *settings, co
 /* psxhip_str_encode_host keeps its MDEC context (device + pinned staging buffers) between calls; this releases it */
 void psxhip_str_release(void);
 
+/* ---------------------------------------------------------------- SPU / VAG / SPUI / VAGI files ---- */
+
+/* The reference's encode_file_spu / encode_file_spui (psxavenc/filefmt.c:212-389, .vag header :95-162) for PCM that is
+ * all there up front: all channels' blocks come from one batched GPU call, the host places them -- leading dummy
+ * block, loop flags, trailing trap block, alignment padding, big-endian .vag header.  Fields mirror args_t. */
+typedef struct {
+	int32_t format;             /* format_t: 2 = SPU, 3 = VAG (mono), 4 = SPUI, 5 = VAGI (interleaved channels) */
+	int32_t audio_frequency;    /* default 44100 */
+	int32_t audio_channels;     /* SPU / VAG: 1 */
+	int32_t audio_interleave;   /* SPUI / VAGI: bytes per channel per chunk, multiple of 16 (default 2048) */
+	int32_t alignment;          /* default 64 (SPU / VAG), 2048 (SPUI / VAGI) */
+	int32_t audio_loop_point;   /* milliseconds, < 0 = none */
+	int32_t enable_loop;        /* FLAG_SPU_ENABLE_LOOP */
+	int32_t no_leading_dummy;   /* FLAG_SPU_NO_LEADING_DUMMY */
+	char name[16];              /* .vag name field: the output file's base name (filefmt.c:150-161) */
+} psxhip_spu_file_settings_t;
+
+/* bytes the file takes for samples_per_channel samples, or < 0 */
+int64_t psxhip_spu_file_size(const psxhip_spu_file_settings_t *settings, int64_t samples_per_channel);
+/* pcm: int16, channels interleaved.  Returns the bytes written (= psxhip_spu_file_size) or < 0. */
+int64_t psxhip_spu_file_encode_host(int device, const psxhip_spu_file_settings_t *settings, const int16_t *pcm,
+                                    int64_t samples_per_channel, uint8_t *out, size_t out_size);
+
 /* ---------------------------------------------------------------- synthetic inputs --------- */
 
 /* Integer-only generators (same function as oracle/synth.c) so benchmarks can fill HBM directly. */

@@ -66,6 +66,7 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     // the reference reads samples[i * pitch] for i < n (adpcm.c:65,110): only (n - 1) * pitch + 1 elements of a
     // stream are the caller's to read -- `samples + channel` with pitch = channels ends before a full n * pitch
     const size_t readable = samples_per_stream ? (size_t)(samples_per_stream - 1) * pitch + 1 : 0;
+    if (n_streams == 1) stream_stride = (int64_t)readable;        // a single stream needs no stride
     std::vector<psxhip_adpcm_chain_t> chains(n_streams);
     std::vector<int32_t> base(n_streams);
     for (int i = 0; i < n_streams; i++) {
@@ -141,6 +142,7 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
     const int units_per_stream = sectors * 18 * upg;
     const int units_per_chain = units_per_stream / ch;
     const size_t per = (size_t)total;
+    if (n_streams == 1) stream_stride = (int64_t)per;             // a single stream needs no stride
     std::vector<psxhip_adpcm_chain_t> chains((size_t)n_streams * ch);
     std::vector<int32_t> base((size_t)n_streams * ch);
     for (int i = 0; i < n_streams; i++)

@@ -329,3 +329,34 @@ def test_empty_and_tiny_inputs():
     got = adpcm.xa_encode_streams(s, np.array([[5, -5, 7]], np.int16), 3)[0]
     want, _ = O.xa_encode(O.XaSettings(1, 0, 37800, 8, 0, 0), np.concatenate([np.array([5, -5, 7], np.int16), np.zeros(5000, np.int16)]), 3)
     assert np.array_equal(got, want)
+
+
+def test_spu_file_framing_vs_reference_golden():
+    """SPU / VAG / SPUI / VAGI files (psxhip_spu_file_encode_host: one batched GPU encode + host framing) against the
+    files the REFERENCE's own psx_audio_spu_encode produces when driven through filefmt.c's framing
+    (tests/golden/spufile_ref.npz, generated by tests/golden/make_spufile_golden.py from oracle/_ref): 88 cases --
+    leading dummy on/off, loop point, loop flag, alignments, ragged tails, 1/2/4 channels, short first chunks."""
+    import hashlib
+    import importlib.util
+    from psxavenc_amd import spufile
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_spufile_golden", os.path.join(here, "golden", "make_spufile_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    gold = np.load(os.path.join(here, "golden", "spufile_ref.npz"))
+    assert len(G.CASES) == len(gold["keys"]) == 88
+    for key, fmt, opts, rec in G.CASES:
+        pcm = G.interleaved_pcm(rec["seed"], rec["kind"], rec["n"], rec["channels"])
+        s = spufile.settings(fmt, channels=rec["channels"], interleave=opts.get("interleave", 2048),
+                             alignment=opts.get("alignment"), loop_point=opts.get("loop_point", -1),
+                             enable_loop=opts.get("enable_loop", False), no_dummy=opts.get("no_dummy", False))
+        got = spufile.encode(s, pcm)
+        assert got.size == int(gold[key + "_size"][0]), key
+        if key + "_bytes" in gold:
+            assert np.array_equal(got, gold[key + "_bytes"]), key
+        assert hashlib.sha256(got.tobytes()).digest() == gold[key + "_sha"].tobytes(), key
+    # SURVEY 8(d) config 1 `spu`: the whole 12 672-byte file, produced by the product's framing
+    sine = G.sine_spu_config()
+    got = spufile.encode(spufile.settings(spufile.FORMAT_SPU), sine)
+    assert got.size == 12672 and got[16:20].tolist() == [0x24, 0x00, 0x70, 0x13]
+    assert np.array_equal(got, gold["config_spu_sine"])
