@@ -14,6 +14,16 @@
  *   - input is never read past sample_count; the reference's stereo path reads up to ~2x past it and
  *     relies on >= 4032 zero samples of padding (adpcm.c:307-308 vs :65,110).  Output equals the
  *     reference's on zero-padded input.
+ *
+ * Interface compatibility notice.  The type names, field layouts, enumerator values and function signatures declared
+ * here are those of psxavenc / libpsxav (https://github.com/WonderfulToolchain/psxavenc),
+ *     Copyright (c) 2019 Ben "GreaseMonkey" Russell
+ *     Copyright (c) 2019, 2020, 2023 Adrian "asie" Siekierka
+ * which is distributed under the zlib licence ("This software is provided 'as-is', without any express or implied
+ * warranty ... 1. The origin of this software must not be misrepresented ... 2. Altered source versions must be plainly
+ * marked as such ... 3. This notice may not be removed or altered from any source distribution.").  THIS FILE IS AN
+ * ALTERED VERSION of that interface, re-declared for the MI355X implementation in this repository; it is not the
+ * original software, and none of the reference's implementation code is part of this repository's product library.
  */
 #ifndef PSXAV_AUDIO_H
 #define PSXAV_AUDIO_H

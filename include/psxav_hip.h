@@ -76,6 +76,12 @@ int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t *ctx, const uint8_t *frames
                                    const int32_t *frame_max_sizes, int uniform_max_size, uint8_t *out,
                                    size_t out_stride, psxhip_mdec_result_t *results);
 
+/* The 8x8 forward DCT alone, exactly as the frame kernel computes it: blocks = n_blocks * 64 level-shifted samples
+ * (-128..127, raster order; what psxavenc/mdec.c:619-633 hands to AVDCT.fdct), coefs = the 64 coefficients per block
+ * in raster order (the in-place result of mdec.c:640).  The FDCT is the one piece of the path the reference takes from
+ * FFmpeg; tools/check_fdct_vs_ffmpeg.c uses this entry point to diff the device arithmetic against a real libavcodec. */
+int psxhip_mdec_fdct_host(int device, const int16_t *blocks, int n_blocks, int16_t *coefs);
+
 /* Name and grid of the kernel the last encode call launched (for bench.py's roofline block). */
 const char *psxhip_mdec_kernel_name(void);
 
@@ -168,6 +174,8 @@ int psxhip_adpcm_session_create(psxhip_adpcm_session_t **session, int device, co
 int psxhip_adpcm_session_run(psxhip_adpcm_session_t *session, const psxhip_adpcm_state_t *start_states,
                              const uint8_t *start_known, int max_passes, psxhip_adpcm_state_t *final_states,
                              int *any_change);
+/* forget the speculative encode: the next psxhip_adpcm_session_run starts over (the samples may have changed) */
+void psxhip_adpcm_session_reset(psxhip_adpcm_session_t *session);
 void psxhip_adpcm_session_destroy(psxhip_adpcm_session_t *session);
 
 /* Pack n_blocks unit records into 16-byte SPU blocks (adpcm.c:367-372).  d_out 16-byte aligned. */

@@ -11,7 +11,7 @@
  * Differences (all invisible to the reference's callers):
  *   - `dct_context` is an opaque handle owned by the library (the reference stores an FFmpeg AVDCT* there,
  *     mdec.h:50); ac_huffman_map, dc_huffman_map, coeff_clamp_map and dct_block_lists stay NULL -- the
- *     tables live in the GPU's LDS and the coefficients in an HBM scratch slab;
+ *     tables and each frame's coefficients live in the GPU's LDS;
  *   - a frame that fits no quant scale aborts with a message (the reference asserts, mdec.c:723);
  *   - nothing is written past frame_output[frame_max_size - 1] (the reference writes one byte past it on
  *     rejected attempts, mdec.c:323-325).
@@ -19,6 +19,16 @@
  *
  * If the including program already has the reference's args.h (format_t, bs_codec_t), define
  * PSXAV_MDEC_NO_ENUMS before including this header.
+ *
+ * Interface compatibility notice.  The type names, field layouts, enumerator values and function signatures declared
+ * here are those of psxavenc / libpsxav (https://github.com/WonderfulToolchain/psxavenc),
+ *     Copyright (c) 2019 Ben "GreaseMonkey" Russell
+ *     Copyright (c) 2019, 2020, 2023 Adrian "asie" Siekierka
+ * which is distributed under the zlib licence ("This software is provided 'as-is', without any express or implied
+ * warranty ... 1. The origin of this software must not be misrepresented ... 2. Altered source versions must be plainly
+ * marked as such ... 3. This notice may not be removed or altered from any source distribution.").  THIS FILE IS AN
+ * ALTERED VERSION of that interface, re-declared for the MI355X implementation in this repository; it is not the
+ * original software, and none of the reference's implementation code is part of this repository's product library.
  */
 #ifndef PSXAV_MDEC_H
 #define PSXAV_MDEC_H

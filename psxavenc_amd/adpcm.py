@@ -300,6 +300,13 @@ class AdpcmSession:
         self.passes += rc
         return final, bool(changed.value)
 
+    def reset(self):
+        """forget the speculative encode: the next run() starts over on the same buffers"""
+        self._L.psxhip_adpcm_session_reset.argtypes = [C.c_void_p]
+        self._L.psxhip_adpcm_session_reset.restype = None
+        self._L.psxhip_adpcm_session_reset(self._h)
+        self.passes = 0
+
     def close(self):
         if self._h:
             self._L.psxhip_adpcm_session_destroy(self._h)

@@ -673,6 +673,10 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     return PSXHIP_OK;
 }
 
+extern "C" void psxhip_adpcm_session_reset(psxhip_adpcm_session_t* s) {
+    if (s) s->speculated = false;        // the next run speculates again from scratch (same buffers, same chunk tables)
+}
+
 extern "C" void psxhip_adpcm_session_destroy(psxhip_adpcm_session_t* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);

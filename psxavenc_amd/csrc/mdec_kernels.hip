@@ -1238,7 +1238,44 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 8x8 forward DCT on its own, exactly as the frame kernel runs it (same fdct8_pk, same lane mapping, same LDS
+// transposes): 6 blocks per wavefront.  in: level-shifted samples (-128..127, what mdec.c:619-633 hands to
+// AVDCT.fdct), out: the 64 coefficients in raster order, like the in-place result of mdec.c:640.  This is the surface
+// tools/check_fdct_vs_ffmpeg.c diffs against a real libavcodec, and tests/test_gpu_mdec.py against the oracle.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mdec_fdct_probe_kernel(const int16_t* in, int16_t* out, int n_blocks) {
+    __shared__ __attribute__((aligned(16))) int16_t tile[6 * kTileStride];
+    const int lane = (int)threadIdx.x;
+    const int blk = lane >> 3, r8 = lane & 7;
+    const int b = (int)blockIdx.x * 6 + blk;
+    const bool live = lane < 48 && b < n_blocks;
+    int d[8];
+    if (live) {
+        const int16_t* p = in + (size_t)b * 64 + r8 * 8;
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = (uint32_t)((int)p[i] + 128) & 0xFFFFu;      // raw sample 0..255
+        fdct8_pk<false>(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[7] | (x[6] << 16), x[5] | (x[4] << 16), d);
+#pragma unroll
+        for (int c = 0; c < 8; c++) tile[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+    }
+    __syncthreads();
+    if (live) {
+        const uint4 q = *(const uint4*)&tile[blk * kTileStride + r8 * 8];
+        fdct8_pk<true>(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+#pragma unroll
+        for (int v = 0; v < 8; v++) out[(size_t)b * 64 + v * 8 + r8] = (int16_t)d[v];
+    }
+}
+
 }  // namespace
+
+extern "C" hipError_t psxhip_mdec_fdct_launch(const int16_t* d_in, int16_t* d_out, int n_blocks, void* stream) {
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mdec_fdct_probe_kernel, dim3((unsigned)((n_blocks + 5) / 6)), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_blocks);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Host side of the kernel (called from psxhip_api.cpp through psxhip_internal.h)

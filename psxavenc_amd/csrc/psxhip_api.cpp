@@ -406,4 +406,30 @@ extern "C" int psxhip_mdec_read_stats(psxhip_mdec_ctx_t* c, unsigned long long* 
     return PSXHIP_OK;
 }
 
+extern "C" int psxhip_mdec_fdct_host(int device, const int16_t* blocks, int n_blocks, int16_t* coefs) {
+    if (!blocks || !coefs || n_blocks < 0) return PSXHIP_EINVAL;
+    for (size_t i = 0; i < (size_t)n_blocks * 64; i++)
+        if (blocks[i] < -128 || blocks[i] > 127) {
+            psxhip_set_error("psxhip_mdec_fdct_host: sample %zu = %d outside -128..127", i, blocks[i]);
+            return PSXHIP_EINVAL;
+        }
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n_blocks == 0) return PSXHIP_OK;
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    const size_t bytes = (size_t)n_blocks * 64 * sizeof(int16_t);
+    HIP_TRY(hipMalloc((void**)&d_in, bytes), PSXHIP_ENOMEM);
+    if (hipMalloc((void**)&d_out, bytes) != hipSuccess) { (void)hipFree(d_in); return PSXHIP_ENOMEM; }
+    hipError_t e = hipMemcpy(d_in, blocks, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = psxhip_mdec_fdct_launch(d_in, d_out, n_blocks, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(coefs, d_out, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        psxhip_set_error("psxhip_mdec_fdct_host: %s", hipGetErrorString(e));
+        return PSXHIP_EDEVICE;
+    }
+    return PSXHIP_OK;
+}
+
 extern "C" const char* psxhip_mdec_kernel_name(void) { return "mdec_encode_frames_kernel"; }

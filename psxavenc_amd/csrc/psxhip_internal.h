@@ -35,6 +35,7 @@ int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
+hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
 
 void psxhip_set_error(const char *fmt, ...);
 

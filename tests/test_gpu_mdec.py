@@ -351,3 +351,30 @@ def test_long_mixed_batch_exercises_hint_checkpoint_and_retry_paths(torch_cuda):
             codec, len(bad), bad[0], bd[bad[0]], res[bad[0], 0], want_res[bad[0], 0])
         assert len(set(res[:, 0].tolist())) > 8         # the batch really spans many scales
         enc.close()
+
+
+def test_device_fdct_matches_oracle_on_200k_blocks():
+    """the DCT alone, through the entry point tools/check_fdct_vs_ffmpeg.c uses off-box (psxhip_mdec_fdct_host): same
+    fdct8_pk / lane mapping / LDS transposes as the frame kernel, against orc_fdct_islow8 on flat, ramp, checkerboard,
+    full-range-noise and extreme blocks"""
+    import ctypes as C
+    from psxavenc_amd import _lib
+    L = _lib.lib()
+    L.psxhip_mdec_fdct_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(99)
+    n = 200000
+    blocks = rng.integers(-128, 128, (n, 64)).astype(np.int16)
+    blocks[0::7] = np.repeat(rng.integers(-128, 128, (len(blocks[0::7]), 1)), 64, axis=1).astype(np.int16)          # flat
+    blocks[1::7] = np.where(rng.integers(0, 2, blocks[1::7].shape) > 0, 127, -128).astype(np.int16)                 # extremes
+    yy, xx = np.mgrid[0:8, 0:8]
+    blocks[2::7] = np.where(((xx ^ yy) & 1).ravel() > 0, 127, -128).astype(np.int16)                                # checkerboard
+    blocks[3::7] = np.clip(rng.integers(-128, 128, (len(blocks[3::7]), 1)) + rng.integers(-4, 5, blocks[3::7].shape), -128, 127).astype(np.int16)
+    blocks[4] = -128
+    blocks[5] = 127
+    got = np.zeros_like(blocks)
+    _lib.check(L.psxhip_mdec_fdct_host(0, blocks.ctypes.data, n, got.ctypes.data))
+    want = blocks.copy()
+    for i in range(n):
+        O.lib().orc_fdct_islow8(O.ptr(want[i], O.i16p))
+    assert np.array_equal(got, want), "first differing block %d" % int(np.nonzero((got != want).any(axis=1))[0][0])
+    assert got[4, 0] == 64 * -128 and got[5, 0] == 64 * 127 and not got[4, 1:].any()     # SURVEY 8(c) sanity pins

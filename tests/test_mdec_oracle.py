@@ -164,3 +164,54 @@ def test_selfgolden_vectors():
             assert res.ravel().tolist() == row[7:7 + 4 * n].tolist()
             sha = hashlib.sha256(out.tobytes()).digest()
             assert sha == g["sha_c%d_%dx%d_b%d_a%d" % (codec, w, h, budget, amp)].tobytes()
+
+
+def test_dct_linear_forms():
+    """the HIP kernel evaluates the islow butterfly as integer LINEAR FORMS (two packed int16 dot products per output,
+    csrc/mdec_kernels.hip fdct8_pk) and feeds the row pass RAW pixels, correcting only the DC term for the level shift.
+    Same arithmetic in numpy (exact integers), against the oracle's butterfly, incl. extreme blocks; also checks that
+    every packed operand fits int16 and every coefficient of the forms fits int16."""
+    K = dict(k298=2446, k390=3196, k541=4433, k765=6270, k899=7373, k1175=9633, k1501=12299, k1847=15137, k1961=16069,
+             k2053=16819, k2562=20995, k3072=25172)
+    A, B, Cc = K["k541"] + K["k765"], K["k541"], K["k541"] - K["k1847"]
+    odd = {
+        7: (K["k298"] - K["k899"] - K["k1961"] + K["k1175"], K["k1175"], K["k1175"] - K["k1961"], K["k1175"] - K["k899"]),
+        5: (K["k1175"], K["k2053"] - K["k2562"] - K["k390"] + K["k1175"], K["k1175"] - K["k2562"], K["k1175"] - K["k390"]),
+        3: (K["k1175"] - K["k1961"], K["k1175"] - K["k2562"], K["k3072"] - K["k2562"] - K["k1961"] + K["k1175"], K["k1175"]),
+        1: (K["k1175"] - K["k899"], K["k1175"] - K["k390"], K["k1175"], K["k1501"] - K["k899"] - K["k390"] + K["k1175"]),
+    }
+    assert all(-32768 <= c <= 32767 for v in odd.values() for c in v) and A <= 32767 and Cc >= -32768
+
+    def pass1d(d, column):
+        d = d.astype(np.int64)
+        s07, s16, s25, s34 = d[..., 0] + d[..., 7], d[..., 1] + d[..., 6], d[..., 2] + d[..., 5], d[..., 3] + d[..., 4]
+        o0, o1, o2, o3 = d[..., 3] - d[..., 4], d[..., 2] - d[..., 5], d[..., 1] - d[..., 6], d[..., 0] - d[..., 7]
+        for v in (s07, s16, s25, s34, o0, o1, o2, o3):
+            assert v.min() >= -32768 and v.max() <= 32767          # packed int16 operands cannot wrap
+        sh = 17 if column else 9
+        rnd = 1 << (sh - 1)
+        out = np.zeros(d.shape, np.int64)
+        if column:
+            out[..., 0] = (s07 + s16 + s25 + s34 + 8) >> 4
+            out[..., 4] = (s07 - s16 - s25 + s34 + 8) >> 4
+        else:
+            out[..., 0] = (s07 + s16 + s25 + s34 - 8 * 128) * 16      # raw pixels: the level shift only moves this term
+            out[..., 4] = (s07 - s16 - s25 + s34) * 16
+        out[..., 2] = (s07 * A + s16 * B - s25 * B - s34 * A + rnd) >> sh
+        out[..., 6] = (s07 * B + s16 * Cc - s25 * Cc - s34 * B + rnd) >> sh
+        for k, (c0, c1, c2, c3) in odd.items():
+            out[..., k] = (o0 * c0 + o1 * c1 + o2 * c2 + o3 * c3 + rnd) >> sh
+        return out.astype(np.int16).astype(np.int64)                 # stored as int16 between and after the passes
+
+    rng = np.random.default_rng(5)
+    blocks = rng.integers(0, 256, (20000, 8, 8))
+    blocks[0], blocks[1] = 0, 255
+    blocks[2] = np.where((np.indices((8, 8)).sum(0) & 1) > 0, 255, 0)
+    blocks[3:1000] = np.where(rng.integers(0, 2, (997, 8, 8)) > 0, 255, 0)
+    rows = pass1d(blocks, False)                                    # row pass on raw pixels
+    cols = pass1d(rows.transpose(0, 2, 1), True).transpose(0, 2, 1)  # column pass
+    want = (blocks - 128).astype(np.int16).reshape(-1, 64).copy()
+    for i in range(want.shape[0]):
+        O.lib().orc_fdct_islow8(O.ptr(want[i], O.i16p))
+    assert np.array_equal(cols.reshape(-1, 64), want.astype(np.int64))
+    assert np.array_equal(cols[:, 0, 0], (blocks - 128).sum(axis=(1, 2)))   # DC == sum of the level-shifted samples (v3 pre-pass)
