@@ -190,6 +190,7 @@ struct Lds {
     uint32_t* stg;          // [stg_words]   macroblock bitstreams, each from a dword boundary, same bit order as `out`
     uint32_t* rec;          // [nmb]         per macroblock (encode order): staging dword offset | stream bits << 16
     uint32_t* mb_off;       // [nmb]         bit offset of each macroblock in the frame's stream
+    int* dc_fn;             // [4 * DC chunks]  v3 DC chains: per 64-element chunk (thr, lo, hi) of its composite + the value entering it
     int16_t* dcv;           // [nmb*6]       per block, encode order: v2 the quantised DC; v3 the quantised DC, then (after the
                             //               chain scan) the DPCM delta -- codes are derived where they are needed
     uint16_t* ac_len16;     // [BS_LUT_SIZE] bits | refinement deficit << 8
@@ -204,12 +205,15 @@ static_assert(sizeof(MdecSearch) == 56 && (S_SEARCH % 2) == 0, "MdecSearch lives
 constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile
 static_assert(kWaveTileBytes >= 384 * 4, "the per-wave code list (384 entries) aliases the tiles");
 
+__host__ __device__ inline int dc_chunks(int nmb) { return 2 * ((nmb + 63) >> 6) + ((4 * nmb + 63) >> 6); }
+
 __host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_words, int waves) {
     size_t b = 0;
     b += (size_t)out_words * 4;
     b += (size_t)stg_words * 4;
     b += (size_t)nmb * 4;         // rec
     b += (size_t)nmb * 4;         // mb_off
+    b += (size_t)dc_chunks(nmb) * 16;   // dc_fn
     b += (size_t)nmb * 6 * 2;     // dcv
     b = (b + 3) & ~(size_t)3;
     b += BS_LUT_SIZE * 2;         // ac_len16
@@ -229,6 +233,7 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg
     L.stg = (uint32_t*)(base + b);        b += (size_t)stg_words * 4;
     L.rec = (uint32_t*)(base + b);        b += (size_t)nmb * 4;
     L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
+    L.dc_fn = (int*)(base + b);           b += (size_t)dc_chunks(nmb) * 16;
     L.dcv = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
     L.ac_len16 = (uint16_t*)(base + b);   b += BS_LUT_SIZE * 2;                    b = (b + 3) & ~(size_t)3;
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
@@ -423,6 +428,36 @@ __device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
     return p;
 }
 
+// step function x -> (x < thr ? lo : hi) and its ordered scan over the 64 lanes (DPP only, no LDS): lane i ends up with
+// f_0 then f_1 ... then f_i composed.  Hillis-Steele inside each 16-lane row, then row_bcast:15 / row_bcast:31.
+struct StepFn {
+    int thr, lo, hi;
+};
+__device__ __forceinline__ StepFn compose(const StepFn& earlier, const StepFn& later) {
+    StepFn r;
+    r.thr = earlier.thr;
+    r.lo = earlier.lo < later.thr ? later.lo : later.hi;
+    r.hi = earlier.hi < later.thr ? later.lo : later.hi;
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ StepFn dpp_stepfn(const StepFn& f) {
+    StepFn e;
+    e.thr = __builtin_amdgcn_update_dpp(f.thr, f.thr, CTRL, 0xF, 0xF, false);
+    e.lo = __builtin_amdgcn_update_dpp(f.lo, f.lo, CTRL, 0xF, 0xF, false);
+    e.hi = __builtin_amdgcn_update_dpp(f.hi, f.hi, CTRL, 0xF, 0xF, false);
+    return e;
+}
+__device__ __forceinline__ void scan_stepfn(StepFn& f, int lane) {
+    StepFn e;
+    e = dpp_stepfn<0x111>(f); if ((lane & 15) >= 1) f = compose(e, f);    // row_shr:1
+    e = dpp_stepfn<0x112>(f); if ((lane & 15) >= 2) f = compose(e, f);    // row_shr:2
+    e = dpp_stepfn<0x114>(f); if ((lane & 15) >= 4) f = compose(e, f);    // row_shr:4
+    e = dpp_stepfn<0x118>(f); if ((lane & 15) >= 8) f = compose(e, f);    // row_shr:8
+    e = dpp_stepfn<0x142>(f); if (lane & 16) f = compose(e, f);           // row_bcast:15 -> rows 1 and 3
+    e = dpp_stepfn<0x143>(f); if (lane >= 32) f = compose(e, f);          // row_bcast:31 -> rows 2 and 3
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register budget: the small shape is compiled for 6 wavefronts per SIMD (<= 80 VGPRs), i.e. two frames in
 // flight per CU.  The hot path is latency-bound (LDS look-ups, DPP scans, ballots), so it is written
@@ -574,7 +609,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         L.dcv[mbe * 6 + b0 + 1] = (int16_t)quant_dc(s1 - 64 * 128);
                     }
                 };
-                constexpr int kDcItems = 4;
+                constexpr int kDcItems = 4;      // loads in flight per lane
                 for (int item = wid; item < total_items; item += kDcItems * kWavesPerGroup) {
                     bool ch[kDcItems], ok[kDcItems];
                     int R[kDcItems], c[kDcItems];
@@ -590,60 +625,87 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
             }
             __syncthreads();
-            if (wid < 3) {
-                // wave 0: Cr chain, wave 1: Cb chain, wave 2: the Y chain (4 blocks per macroblock).
-                // Element i maps last -> new_last:
-                //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
-                //   dc % 4 == 2 : last < dc ? dc + 2 : dc - 2           (tie, rounds away from zero)
-                // Both are step functions (thr, lo, hi); composition g(f(x)) = (thr_f, g(lo_f), g(hi_f)),
-                // so the chain is an inclusive scan under composition.
-                const int count = wid == 2 ? 4 * nmb : nmb;
-                int carry = 0, bits = 0;
-                for (int base = 0; base < count; base += 64) {
-                    const int i = base + lane;
-                    const bool live = i < count;
-                    const int idx = wid == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + wid);
+            // The DPCM chains (mdec.c:454-479): Cr, Cb and Y (4 blocks per macroblock), each in encode order.
+            // Element i maps last -> new_last:
+            //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
+            //   dc % 4 == 2 : last < dc ? dc + 2 : dc - 2           (tie, rounds away from zero)
+            // Both are step functions (thr, lo, hi); composition g(f(x)) = (thr_f, g(lo_f), g(hi_f)) is associative, so
+            // a chain is an inclusive scan under composition.  Chunks of 64 elements are spread over all wavefronts:
+            // (A) scan inside each chunk, keep the chunk's total; (B) scan the totals of each chain -> the value
+            // entering every chunk; (C) scan again inside each chunk, apply, emit deltas.
+            {
+                const int cc = (nmb + 63) >> 6, cy = (4 * nmb + 63) >> 6, n_chunks = 2 * cc + cy;
+                auto chunk_of = [&](int q, int& chain, int& base, int& count) {
+                    chain = q < cc ? 0 : (q < 2 * cc ? 1 : 2);
+                    base = (q - (chain == 0 ? 0 : (chain == 1 ? cc : 2 * cc))) << 6;
+                    count = chain == 2 ? 4 * nmb : nmb;
+                };
+                auto element = [&](int chain, int i, bool live, int& idx) -> StepFn {
+                    idx = chain == 2 ? ((i >> 2) * 6 + 2 + (i & 3)) : (i * 6 + chain);
                     const int dc = live ? (int)L.dcv[idx] : 0;
-                    int thr, lo, hi;
+                    StepFn f;
                     if ((dc & 3) == 2) {
-                        thr = dc; lo = dc + 2; hi = dc - 2;
+                        f.thr = dc; f.lo = dc + 2; f.hi = dc - 2;
                     } else {
                         const int a = dc < 0 ? -dc : dc;
                         const int rq = ((a + 2) >> 2) << 2;
-                        thr = 0; lo = hi = dc < 0 ? -rq : rq;
+                        f.thr = 0; f.lo = f.hi = dc < 0 ? -rq : rq;
                     }
-                    if (!live) { thr = -100000; lo = hi = 0; }   // dead lanes sit after all live ones, never feed them
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int pthr = __shfl_up(thr, off, 64);
-                        const int plo = __shfl_up(lo, off, 64);
-                        const int phi = __shfl_up(hi, off, 64);
-                        if (lane >= off) {
-                            // me(prev(x)): apply my current (thr, lo, hi) to the predecessor's two outputs
-                            const int nlo = plo < thr ? lo : hi;
-                            const int nhi = phi < thr ? lo : hi;
-                            thr = pthr; lo = nlo; hi = nhi;
-                        }
+                    if (!live) { f.thr = -100000; f.lo = f.hi = 0; }   // dead lanes sit after all live ones, never feed them
+                    return f;
+                };
+                // (A)
+                for (int q = wid; q < n_chunks; q += kWavesPerGroup) {
+                    int chain, base, count, idx;
+                    chunk_of(q, chain, base, count);
+                    StepFn f = element(chain, base + lane, base + lane < count, idx);
+                    scan_stepfn(f, lane);
+                    if (lane == 63) { L.dc_fn[4 * q + 0] = f.thr; L.dc_fn[4 * q + 1] = f.lo; L.dc_fn[4 * q + 2] = f.hi; }
+                }
+                __syncthreads();
+                // (B) wavefront c scans chain c's chunk totals (lanes = chunks)
+                if (wid < 3) {
+                    const int q0 = wid == 0 ? 0 : (wid == 1 ? cc : 2 * cc), nq = wid == 2 ? cy : cc;
+                    int carry = 0;
+                    for (int b0 = 0; b0 < nq; b0 += 64) {
+                        const int j = b0 + lane;
+                        StepFn f;
+                        f.thr = -100000; f.lo = f.hi = 0;
+                        if (j < nq) { f.thr = L.dc_fn[4 * (q0 + j) + 0]; f.lo = L.dc_fn[4 * (q0 + j) + 1]; f.hi = L.dc_fn[4 * (q0 + j) + 2]; }
+                        scan_stepfn(f, lane);
+                        const int cur = carry < f.thr ? f.lo : f.hi;          // value after chunk j
+                        int before = __builtin_amdgcn_update_dpp(carry, cur, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                        if (j < nq) L.dc_fn[4 * (q0 + j) + 3] = before;       // value entering chunk j
+                        carry = __builtin_amdgcn_readlane(cur, 63);
                     }
-                    const int cur = carry < thr ? lo : hi;            // last value after element i
-                    int prev = __shfl_up(cur, 1, 64);
-                    if (lane == 0) prev = carry;
-                    int delta = (cur - prev) >> 2;                      // exact: both multiples of 4
-                    if (CODEC == 2) {                                   // v3dc wrap (mdec.c:469-474)
+                }
+                __syncthreads();
+                // (C)
+                int bits = 0;
+                for (int q = wid; q < n_chunks; q += kWavesPerGroup) {
+                    int chain, base, count, idx;
+                    chunk_of(q, chain, base, count);
+                    const bool live = base + lane < count;
+                    StepFn f = element(chain, base + lane, live, idx);
+                    scan_stepfn(f, lane);
+                    const int cin = L.dc_fn[4 * q + 3];
+                    const int cur = cin < f.thr ? f.lo : f.hi;               // last value after this element
+                    const int prev = __builtin_amdgcn_update_dpp(cin, cur, 0x138, 0xF, 0xF, false);
+                    int delta = (cur - prev) >> 2;                             // exact: both multiples of 4
+                    if (CODEC == 2) {                                          // v3dc wrap (mdec.c:469-474)
                         if (delta < -0x80) delta += 0x100;
                         else if (delta > 0x80) delta -= 0x100;
                     }
                     int dlen;
                     uint32_t dcode;
-                    dc_code<CODEC>(delta, wid == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
+                    dc_code<CODEC>(delta, chain == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
                     if (live) {
                         L.dcv[idx] = (int16_t)delta;
                         bits += dlen;
                     }
-                    carry = __shfl(cur, 63, 64);
                 }
                 bits = wave::reduce_add(bits);
-                if (lane == 0) atomicAdd(&L.scalars[S_DC_BITS], bits);
+                if (lane == 0 && bits) atomicAdd(&L.scalars[S_DC_BITS], bits);
             }
             __syncthreads();
         }
