@@ -66,7 +66,7 @@ struct FrameJob {
     int stg_words;           // LDS dwords of the macroblock staging area
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see PassCursor
-    unsigned int* ticket;    // [2]: next frame to hand out, workgroups finished (self-resetting)
+    unsigned int* ticket;    // [4]: [2] = last answer | budget << 8 of any group (a hint that survives launches),: next frame to hand out, workgroups finished (self-resetting)
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
@@ -96,7 +96,7 @@ enum {
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
     S_HINT_BUDGET,      // ... and its budget
-    S_PAD1,
+    S_SHARED_HINT,      // answer | budget << 8 of the last frame any group finished before this group started
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // first group on a SIMD holds the low slots); the groups take turns at raised priority, one macroblock at a time.
     const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
     const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
-    if (tid == 0) L.scalars[S_HINT] = 0;
+    if (tid == 0) { L.scalars[S_HINT] = 0; L.scalars[S_SHARED_HINT] = (int)job.ticket[2]; }
     unsigned long long t_start = 0, t_mark = 0;
     auto mark = [&](int phase) {       // diagnostics: time since the previous mark goes to `phase`
         if (job.stats && tid == 0) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // ---- reset per-frame state
         for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET) L.scalars[tid] = 0;
+        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
         __syncthreads();
 
         // =====================================================================================
@@ -788,11 +788,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             for (int b = 0; b < 6; b++) cfp[i][b] = pi < n_pilot ? cf[b] : 0.0f;
         }
         if (tid == 0) {
-            if (hint >= 2 && hint <= 63) {
+            int h0 = hint;
+            if (h0 < 1) {
+                // no frame of its own yet: another group's last answer for the same budget is a good place to start looking
+                const int sh = L.scalars[S_SHARED_HINT];
+                if ((sh >> 8) == max_size) h0 = sh & 0xFF;
+            }
+            if (h0 >= 2 && h0 <= 63) {
                 // frames handled back to back by one group tend to need the same scale: two evaluations confirm it
                 L.scalars[S_PILOT_N] = 2;
-                L.scalars[S_PILOT_SCALE0 + 0] = hint - 1;
-                L.scalars[S_PILOT_SCALE0 + 1] = hint;
+                L.scalars[S_PILOT_SCALE0 + 0] = h0 - 1;
+                L.scalars[S_PILOT_SCALE0 + 1] = h0;
             } else {
                 L.scalars[S_PILOT_N] = 4;
                 L.scalars[S_PILOT_SCALE0 + 0] = 1;
@@ -1134,7 +1140,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     wave_sync();   // the list is overwritten by the next macroblock's tiles
                 }
             }
-            if (WAVES == kWavesSmall) __builtin_amdgcn_s_setprio(0);
+            // outside the passes a group runs short, latency-bound phases (decisions, scans, merge): let them cut ahead of the
+            // partner group's VALU stream instead of queueing behind it
+            if (WAVES == kWavesSmall) {
+                switch ((job.prio_pattern >> 16) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
             if (!aborted) flush();
             __syncthreads();
             if (tid == 0) {
@@ -1183,7 +1198,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
 
         const int scale = L.scalars[S_RESULT];
-        if (tid == 0) { L.scalars[S_HINT] = scale < 64 ? scale : 0; L.scalars[S_HINT_BUDGET] = max_size; }
+        if (tid == 0) {
+            L.scalars[S_HINT] = scale < 64 ? scale : 0;
+            L.scalars[S_HINT_BUDGET] = max_size;
+            if (scale < 64) job.ticket[2] = (unsigned)scale | ((unsigned)max_size << 8);
+        }
         uint8_t* outp = job.out + (size_t)f * job.out_stride;
 
         if (scale >= 64 || bad_budget) {

@@ -182,11 +182,11 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     // opt the kernels into the whole LDS once (contexts with different geometries share the kernel attribute)
     HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
     c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
-    c->prio_pattern = 0xEE11u;
+    c->prio_pattern = 0x2EE11u;
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
 
-    HIP_TRY(hipMalloc((void**)&c->d_ticket, 2 * sizeof(unsigned int)), PSXHIP_ENOMEM);
-    HIP_TRY(hipMemset(c->d_ticket, 0, 2 * sizeof(unsigned int)), PSXHIP_EDEVICE);
+    HIP_TRY(hipMalloc((void**)&c->d_ticket, 4 * sizeof(unsigned int)), PSXHIP_ENOMEM);
+    HIP_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned int)), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
     if (const char* e = getenv("PSXHIP_MDEC_STATS")) {
         if (atoi(e)) {
