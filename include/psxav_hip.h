@@ -50,8 +50,9 @@ typedef struct psxhip_mdec_ctx psxhip_mdec_ctx_t;
 /* codec: 0 = BS v2, 1 = v3, 2 = v3dc (bs_codec_t, psxavenc/args.h:61-65).
  * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 each.
  * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging).
- * A frame's working set (budget + ~19 bytes per macroblock + ~45 KiB) must fit the CU's 160 KiB LDS, else
- * PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to ~64 KiB budgets. */
+ * A frame's working set (2 x budget + ~30 bytes per macroblock + ~37 KiB) must fit the CU's 160 KiB LDS, else
+ * PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to 44 228-byte budgets;
+ * psxhip_mdec_query_geometry() tells before creating a context. */
 int psxhip_mdec_create(psxhip_mdec_ctx_t **ctx, int device, int codec, int width, int height,
                        int max_frame_size);
 void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
@@ -88,7 +89,7 @@ const char *psxhip_mdec_kernel_name(void);
 /* What a geometry costs, before creating a context for it.  A frame's working set lives in the CU's
  * 160 KiB LDS: about 2 * max_frame_size + 28 bytes per macroblock + ~37 KiB (two workgroups per CU when twice
  * that fits, else one).  fits == 0 means psxhip_mdec_create would return PSXHIP_EINVAL; max_frame_size_limit
- * is the largest budget this frame size supports (e.g. 320x240: ~58 KiB, 640x480: ~49 KiB). */
+ * is the largest budget this frame size supports (320x240: 56 716 bytes, 640x480: 45 244, 640x512: 44 228). */
 typedef struct {
 	int32_t fits;
 	int32_t groups_per_cu;          /* frames in flight per compute unit (2 or 1) */
@@ -204,6 +205,10 @@ int psxhip_xa_encode_streams_host(int device, int format, int stereo, int freque
                                   int channel_number, const int16_t *samples, int n_streams, int64_t stream_stride,
                                   int samples_per_stream, const int32_t *lbas, psxhip_adpcm_state_t *states,
                                   uint8_t *out, int64_t out_stride, int finalize);
+
+/* The host-buffer ADPCM entry points keep their device scratch buffers per calling thread between calls (the reference
+ * calls them once per 28 samples / once per sector); this releases the calling thread's. */
+void psxhip_release_scratch(void);
 
 /* ---------------------------------------------------------------- STR / STRCD / STRV muxer -- */
 

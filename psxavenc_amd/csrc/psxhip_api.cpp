@@ -328,6 +328,9 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
     const size_t dstride = ((size_t)max_size + 3) & ~(size_t)3;
     // chunk: enough frames to fill the GPU a few times over, small enough that staging stays cache- and latency-friendly
     int chunk = c->groups_max * 2;
+    const size_t staging_cap = (size_t)96 << 20;                  // pinned bytes per staging buffer
+    if ((size_t)chunk * fsz > staging_cap) chunk = (int)(staging_cap / fsz);
+    if (chunk < 1) chunk = 1;
     if (chunk > n_frames) chunk = n_frames;
     if (chunk > c->cap_frames || dstride > c->cap_out_stride) {
         const int cap = chunk > c->cap_frames ? chunk : c->cap_frames;

@@ -35,14 +35,54 @@ inline void pick_chunking(long long total_units, int* chunk_units, int* warmup_u
     *warmup_units = w < 16 ? 16 : (w > 64 ? 64 : w);
 }
 
+// Device scratch of the host-buffer entry points.  The reference calls psx_audio_spu_encode once per 28 samples and
+// psx_audio_xa_encode once per sector (filefmt.c:243,184): allocating half a dozen device buffers per call would cost far
+// more than the encode, so every host thread keeps its scratch buffers between calls (grown on demand, released by
+// psxhip_release_scratch() or with the process).
+struct ScratchPool {
+    static constexpr int kSlots = 8;
+    void* p[kSlots] = {nullptr};
+    size_t cap[kSlots] = {0};
+    int device = -1;
+    void release() {
+        for (int i = 0; i < kSlots; i++) {
+            if (p[i]) (void)hipFree(p[i]);
+            p[i] = nullptr;
+            cap[i] = 0;
+        }
+    }
+    hipError_t get(int slot, int dev, size_t n, void** out) {
+        if (dev != device) {
+            release();
+            device = dev;
+        }
+        if (n > cap[slot]) {
+            if (p[slot]) (void)hipFree(p[slot]);
+            p[slot] = nullptr;
+            cap[slot] = 0;
+            const size_t want = n + n / 2 + 256;
+            hipError_t e = hipMalloc(&p[slot], want);
+            if (e != hipSuccess) return e;
+            cap[slot] = want;
+        }
+        *out = p[slot];
+        return hipSuccess;
+    }
+};
+thread_local ScratchPool g_pool;
+thread_local int g_pool_device = 0;
+
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    int slot;
+    explicit DevBuf(int s) : slot(s) {}
+    hipError_t alloc(size_t n) { return g_pool.get(slot, g_pool_device, n ? n : 4, &p); }
     template <typename T> T* as() { return (T*)p; }
 };
 
 }  // namespace
+
+extern "C" void psxhip_release_scratch(void) { g_pool.release(); }
 
 extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples, int n_streams, int64_t stream_stride,
                                               int pitch, int samples_per_stream, psxhip_adpcm_state_t* states,
@@ -77,7 +117,8 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
         chains[i].unit_stride = 1;
         base[i] = i * n_units;
     }
-    DevBuf d_s, d_c, d_b, d_st, d_u, d_o;
+    g_pool_device = device;
+    DevBuf d_s(0), d_c(1), d_b(2), d_st(3), d_u(4), d_o(5);
     HIP_TRY(d_s.alloc(per * n_streams * sizeof(int16_t)), PSXHIP_ENOMEM);
     HIP_TRY(d_c.alloc(chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
     HIP_TRY(d_b.alloc(base.size() * sizeof(int32_t)), PSXHIP_ENOMEM);
@@ -159,7 +200,8 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
     if (finalize)
         for (int i = 0; i < n_streams; i++) eof[(size_t)i * sectors + sectors - 1] = 1;
 
-    DevBuf d_s, d_c, d_b, d_st, d_u, d_o, d_e;
+    g_pool_device = device;
+    DevBuf d_s(0), d_c(1), d_b(2), d_st(3), d_u(4), d_o(5), d_e(6);
     HIP_TRY(d_s.alloc(per * n_streams * sizeof(int16_t)), PSXHIP_ENOMEM);
     HIP_TRY(d_c.alloc(chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
     HIP_TRY(d_b.alloc(base.size() * sizeof(int32_t)), PSXHIP_ENOMEM);

@@ -5,6 +5,19 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
 from psxavenc_amd.mdec import MdecEncoder
+import ctypes as C
+from psxavenc_amd import _lib
+
+
+def budget_limit(codec, w, h):
+    class Geo(C.Structure):
+        _fields_ = [("fits", C.c_int32), ("groups_per_cu", C.c_int32), ("wavefronts_per_group", C.c_int32), ("frames_in_flight", C.c_int32),
+                    ("max_frame_size_limit", C.c_int32), ("reserved", C.c_int32), ("lds_bytes_per_group", C.c_int64), ("lds_bytes_per_cu", C.c_int64)]
+    geo = Geo()
+    _lib.check(_lib.lib().psxhip_mdec_query_geometry(0, codec, w, h, 8192, C.byref(geo)))
+    return int(geo.max_frame_size_limit)
+
+
 rng = np.random.default_rng(777)
 total = bad = 0
 t0 = time.time()
@@ -16,6 +29,7 @@ for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     frames = O.synth_frames(w, h, n, seed=int(rng.integers(1, 1 << 30)), amp=amp, first=int(rng.integers(0, 100000)))
     lo = 8 + 2 * (((w // 16) * (h // 16) * 6 * 12 + 10 + 15) // 16)
     budgets = rng.integers(lo + 200, lo + 200 + int(rng.integers(500, 40000)), n).astype(np.int32)
+    budgets = np.minimum(budgets, budget_limit(codec, w, h))     # a frame's working set has to fit the CU's LDS
     want, want_res, rc = O.mdec_encode(codec, w, h, frames, budgets, stride=int(budgets.max()))
     if rc != 0:
         # some frame fits no scale: encode one by one
