@@ -765,8 +765,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         //      at a few scales, scaled up to the frame, predict the answer
         // A group that has just encoded a frame with the same budget skips the pilot and starts from that frame's answer
         // (consecutive tickets are neighbouring frames); the quarter-pass checkpoint catches the cases where it is off.
-        const int hint = L.scalars[S_HINT];
-        const bool trust_hint = hint >= 1 && hint <= 63 && L.scalars[S_HINT_BUDGET] == max_size;
+        // A group's first frame borrows the answer of the last frame ANY group finished before this launch's groups started
+        // (the tail of the previous batch -- temporally adjacent when batches follow each other in a stream).
+        int hint = L.scalars[S_HINT];
+        int hint_budget = L.scalars[S_HINT_BUDGET];
+        if (hint < 1) {
+            const int sh = L.scalars[S_SHARED_HINT];
+            hint = sh & 0xFF;
+            hint_budget = sh >> 8;
+        }
+        const bool trust_hint = hint >= 1 && hint <= 63 && hint_budget == max_size;
         if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
         if (trust_hint) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
