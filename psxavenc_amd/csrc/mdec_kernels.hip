@@ -727,7 +727,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             phi = *(const uint2*)(p + pl.hi_off);
         };
         // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
-        auto dct_mb = [&](int mbe_cur, bool have_next, int next_fx, int next_fy) {
+        auto dct_mb = [&](bool have_next, int next_fx, int next_fy) {
             const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[0]);
             const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[1]);
             const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, pl.sel[2]);
@@ -745,12 +745,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
                 const uint4 q = *(const uint4*)&tileT[blk * kTileStride + r8 * 8];
                 fdct8_pk<true>(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
-                // -- column 0 holds the block's DC term in d[0]: v2 quantises it here; 0 is stored in its place so that
-                //    the AC path sees "no coefficient" at scan position 0
-                if (r8 == 0) {
-                    if (CODEC == 0) L.dcv[mbe_cur * 6 + blk] = (int16_t)quant_dc(d[0]);
-                    d[0] = 0;
-                }
+                // -- column 0 holds the block's DC term in d[0].  v2: its quantised value (mdec.c:447-453) takes its place at
+                //    scan position 0 and travels with the block's DC slot in the code list.  v3: the DC codes come from the
+                //    pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated as an AC coefficient.
+                if (r8 == 0) d[0] = CODEC == 0 ? quant_dc(d[0]) : 0;
                 char* zb = (char*)tileZ;
 #pragma unroll
                 for (int v = 0; v < 8; v++) {
@@ -787,9 +785,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (pi < n_pilot) {
                 const MbCursor pc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
                 fetch(pc.fx, pc.fy);
-                dct_mb(pc.fx * ny + pc.fy, false, 0, 0);
+                dct_mb(false, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 6; b++) cf[b] = (float)(int)tileZ[b * kZStride + lane];
+                for (int b = 0; b < 6; b++) cf[b] = lane == 0 ? 0.0f : (float)(int)tileZ[b * kZStride + lane];
                 wave_sync();
             }
 #pragma unroll
@@ -909,7 +907,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
             int acc_cnt = 0;             // per lane: bits | deficit << 16 over this wavefront's macroblocks (count scale)
             int acc_edef = 0;            // per lane: deficit over the emitted codes
-            int acc_codes = 0;           // per lane: codes emitted (AC codes + DC slots)
+            int n_codes = 0;             // wave-uniform: codes emitted (AC codes + DC slots)
             int emit_bits = 0, mb_done = 0;  // wave-uniform
             // compaction threshold of this lane: smallest |n| that quantises to non-zero at the list's scale
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
@@ -923,13 +921,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     acc_cnt = 0;
                 }
                 if (emit_scale) {
-                    const int td = wave::reduce_add(acc_edef), tc = wave::reduce_add(acc_codes);
+                    const int td = wave::reduce_add(acc_edef), tc = n_codes;
                     if (lane == 0) {
                         atomicAdd(&L.scalars[S_EMIT_BITS], emit_bits);
                         atomicAdd(&L.scalars[S_EMIT_D], td);
                         atomicAdd(&L.scalars[S_NNZ], tc - 6 * mb_done);      // AC codes = all codes - the DC slots
                     }
-                    acc_edef = 0; acc_codes = 0; emit_bits = 0;
+                    acc_edef = 0; n_codes = 0; emit_bits = 0;
                 }
                 if (lane == 0) atomicAdd(&L.scalars[S_CK_DONE], mb_done);
                 mb_done = 0;
@@ -971,7 +969,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     cur = nxt;
                     continue;
                 }
-                dct_mb(mbe, nxt_valid, nxt.fx, nxt.fy);
+                dct_mb(nxt_valid, nxt.fx, nxt.fy);
                 cur = nxt;
                 mb_done++;
 
@@ -984,7 +982,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     // count-only pass (rare: closing a gap below a scale that is already staged)
                     float cff[6];
 #pragma unroll
-                    for (int b = 0; b < 6; b++) cff[b] = (float)ci[b];
+                    for (int b = 0; b < 6; b++) cff[b] = lane == 0 ? 0.0f : (float)ci[b];
                     const int a = count_mb(cff, kc, lc, L.ac_len16);
                     acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
                 } else {
@@ -1007,7 +1005,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (count_scale && !list_low) {
                         float cff[6];
 #pragma unroll
-                        for (int b = 0; b < 6; b++) cff[b] = (float)ci[b];
+                        for (int b = 0; b < 6; b++) cff[b] = lane == 0 ? 0.0f : (float)ci[b];
                         const int a = count_mb(cff, kc, lc, L.ac_len16);
                         acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
                     }
@@ -1040,7 +1038,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const bool is_dc = k == 0;
                         const bool is_ac = live && !is_dc;
                         const float magf = (float)(e & 0xFFFFu);
-                        const uint64_t dcmask = wave::ballot(is_dc);
                         cnt16 = 0;
                         int kprev;
                         // the quantiser constants belong to the entry's scan position k, i.e. they sit in lane k's registers
@@ -1080,16 +1077,28 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         len = (int)(entry >> 24);
                         code = len == BS_ESCAPE_BITS ? esc : ((entry & 0x1FFFFu) | (neg ? 1u : 0u));
                         deficit = (int)((entry >> BS_LUT_DEFICIT_SHIFT) & 0xFu);
-                        // DC slots: block index = number of DC slots before this one in the macroblock's list
-                        if (is_dc) {
-                            const int bi = bcarry + wave::popc_below(dcmask);
-                            dc_code<CODEC>((int)L.dcv[mbe * 6 + bi], bi >= 2, L.dc_plen, L.dc_prefix, len, code);
-                            if (bi > 0) {                               // carry the previous block's end-of-block code
-                                code |= 2u << len;
-                                len += 2;
+                        if (CODEC == 0) {
+                            // v2 DC slot: the entry carries the quantised DC as sign / magnitude; 10 bits (mdec.c:451-453), every
+                            // slot but the macroblock's first also carries the previous block's end-of-block code
+                            if (is_dc) {
+                                const uint32_t m = e & 0xFFFFu;
+                                const uint32_t dcv10 = (neg ? 0u - m : m) & 0x3FFu;
+                                code = i != 0 ? dcv10 | (2u << 10) : dcv10;
+                                len = i != 0 ? 12 : 10;
                             }
+                        } else {
+                            // v3 DC slots: block index = number of DC slots before this one in the macroblock's list
+                            const uint64_t dcmask = wave::ballot(is_dc);
+                            if (is_dc) {
+                                const int bi = bcarry + wave::popc_below(dcmask);
+                                dc_code<CODEC>((int)L.dcv[mbe * 6 + bi], bi >= 2, L.dc_plen, L.dc_prefix, len, code);
+                                if (bi > 0) {                               // carry the previous block's end-of-block code
+                                    code |= 2u << len;
+                                    len += 2;
+                                }
+                            }
+                            bcarry += (int)__builtin_popcountll(dcmask);
                         }
-                        bcarry += (int)__builtin_popcountll(dcmask);
                     };
                     // staging for a macroblock of `total` bits (+ the last block's end-of-block code): returns its bit position
                     bool have_room = true;
@@ -1108,7 +1117,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         emit_bits += (int)mb_bits;
                         return (uint32_t)off * 32u;
                     };
-                    int mb_codes = 0;        // codes of the emit scale incl. the six DC slots (per lane partial)
                     if (count <= 64) {
                         int len, deficit, cnt16;
                         uint32_t code;
@@ -1117,8 +1125,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
                         if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                         acc_edef += deficit;
-                        acc_cnt += (cnt16 & 0xFF) | ((cnt16 >> 8) << 16);
-                        mb_codes += len ? 1 : 0;
+                        acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
+                        n_codes += (int)__builtin_popcountll(wave::ballot(len != 0));
                     } else {
                         // longer lists: add up the lengths first (the allocation needs the macroblock's total), then write
                         int lsum = 0;
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             uint32_t code;
                             chunk(base, list_low, len, code, deficit, cnt16);
                             lsum += len;
-                            acc_cnt += (cnt16 & 0xFF) | ((cnt16 >> 8) << 16);
+                            acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
                         }
                         uint32_t pos = stage_alloc((uint32_t)wave::reduce_add(lsum));
                         kcarry_a = 0;
@@ -1141,10 +1149,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                             acc_edef += deficit;
-                            mb_codes += len ? 1 : 0;
+                            n_codes += (int)__builtin_popcountll(wave::ballot(len != 0));
                         }
                     }
-                    acc_codes += mb_codes;
                     wave_sync();   // the list is overwritten by the next macroblock's tiles
                 }
             }
