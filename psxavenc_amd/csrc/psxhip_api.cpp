@@ -99,7 +99,8 @@ int mdec_geometry(int width, int height, int max_frame_size, size_t lds_cu, int*
     const int ow = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
     const int sw = (max_frame_size + 3) / 4 + nmb + 2;
     if (sw > 0xFFFF) return 0;                      // staging offsets are 16-bit
-    const int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow, sw, 0) > lds_cu;
+    int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow, sw, 0) > lds_cu;
+    if (const char* e = getenv("PSXHIP_MDEC_LARGE")) { if (atoi(e)) lg = 1; }   // experiments
     const size_t need = psxhip_mdec_lds_bytes(nmb, ow, sw, lg);
     if (large) *large = lg;
     if (out_words) *out_words = ow;
@@ -182,6 +183,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     // opt the kernels into the whole LDS once (contexts with different geometries share the kernel attribute)
     HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
     c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
+    if (const char* e = getenv("PSXHIP_MDEC_GRID")) { const int g = atoi(e); if (g > 0 && g < c->groups_max) c->groups_max = g; }   // experiments
     c->prio_pattern = 0x2EE11u;
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
 
