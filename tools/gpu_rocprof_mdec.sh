@@ -9,8 +9,11 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-cmd="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --launches-per-step 1 $*"
-rocprofv3 --kernel-trace --stats -d $out/kt -o r -- $cmd > $out/kt.log 2>&1
+# kernel-trace: the bench's own command line (defaults: 20 steps x 16 launches), so that the kernel's average duration here
+# and bench.py's HIP-event mean are measurements of the same thing; PMC passes: a shorter run of the same workload
+full="python bench.py --no-cpu-baseline $*"
+cmd="python bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d $out/kt -o r -- $full > $out/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o r -- $cmd > $out/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $out/sq -o r -- $cmd > $out/sq.log 2>&1
