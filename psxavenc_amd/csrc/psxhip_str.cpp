@@ -216,62 +216,90 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
 
     // ---- interleave (filefmt.c:450-503)
     const int at = s->format == FORMAT_STR ? 0x08 : (s->format == FORMAT_STRCD ? 0x18 : 0x00);     // mdec.c:822-829
-    int frame = -1, offset = 0, budget = 0, audio_sector = 0;
+    // which frame slice / audio sector lands in which sector: a short serial walk; the sectors themselves (2 KiB of copying
+    // and a 2 KiB EDC each) are then built by a few threads, each on its own range
+    const int ns = pl.pub.n_sectors;
+    std::vector<int32_t> sec_frame((size_t)ns), sec_off((size_t)ns);        // video: frame, byte offset; audio: -1, audio sector
     long long qsum = 0;
-    uint8_t sector[PSX_CDROM_SECTOR_SIZE];
-    for (int n = 0; n < pl.pub.n_sectors; n++) {
-        uint8_t* dst = out + (size_t)n * ssz;
-        if (is_video_sector(s, pl.pub.interleave, pl.video_per_block, n)) {
-            memset(sector, 0, sizeof sector);            // the reference's buffer is an uninitialised stack array
-            // init_sector_buffer_video, filefmt.c:73-91
-            psx_cdrom_sector_xa_subheader_t* sub = nullptr;
-            if (s->format == FORMAT_STRCD) {
-                psx_cdrom_init_sector((psx_cdrom_sector_t*)sector, n, PSX_CDROM_SECTOR_TYPE_MODE2_FORM1);
-                sub = ((psx_cdrom_sector_t*)sector)->mode2.subheader;
-            } else if (s->format == FORMAT_STR) {
-                sub = (psx_cdrom_sector_xa_subheader_t*)sector;
+    {
+        int frame = -1, offset = 0, budget = 0, audio_sector = 0;
+        for (int n = 0; n < ns; n++) {
+            if (is_video_sector(s, pl.pub.interleave, pl.video_per_block, n)) {
+                if (offset >= budget) {                    // encode_sector_str moves on to the next frame, mdec.c:766-779
+                    frame++;
+                    budget = pl.budgets[(size_t)frame];
+                    offset = 0;
+                    qsum += res[(size_t)frame].quant_scale;
+                }
+                sec_frame[(size_t)n] = frame;
+                sec_off[(size_t)n] = offset;
+                offset += 2016;
+            } else {
+                sec_frame[(size_t)n] = -1;
+                sec_off[(size_t)n] = audio_sector++;
             }
-            if (sub) {
-                sub->file = (uint8_t)s->audio_xa_file;
-                sub->channel = (uint8_t)(s->audio_xa_channel & PSX_CDROM_SECTOR_XA_CHANNEL_MASK);
-                sub->submode = PSX_CDROM_SECTOR_XA_SUBMODE_DATA | PSX_CDROM_SECTOR_XA_SUBMODE_RT;
-                sub->coding = 0;
-                sub[1] = sub[0];
-            }
-            // encode_sector_str, mdec.c:757-836, on the already encoded frames
-            if (offset >= budget) {
-                frame++;
-                budget = pl.budgets[(size_t)frame];
-                offset = 0;
-                qsum += res[(size_t)frame].quant_scale;
-            }
-            const uint8_t* fo = bs.data() + (size_t)frame * ostride;
-            uint8_t* hd = sector + at;
-            put_le16(hd + 0x00, 0x0160);
-            put_le16(hd + 0x02, (unsigned)s->str_video_id);
-            put_le16(hd + 0x04, (unsigned)(offset / 2016));
-            put_le16(hd + 0x06, (unsigned)(budget / 2016));
-            put_le32(hd + 0x08, (unsigned)(frame + 1));                         // frame_index counts from 1
-            put_le32(hd + 0x0C, (unsigned)res[(size_t)frame].bytes_used);
-            put_le16(hd + 0x10, (unsigned)s->video_width);
-            put_le16(hd + 0x12, (unsigned)s->video_height);
-            memcpy(hd + 0x14, fo, 8);
-            put_le32(hd + 0x1C, 0);
-            memcpy(hd + 0x20, fo + offset, 2016);
-            offset += 2016;
-            psx_cdrom_calculate_checksums((psx_cdrom_sector_t*)sector, PSX_CDROM_SECTOR_TYPE_MODE2_FORM1);
-            memcpy(dst, sector, ssz);
-        } else {
-            memcpy(dst, xa_out.data() + (size_t)audio_sector * ssz, ssz);
-            if (s->format == FORMAT_STRCD) {
-                // the audio sectors were assembled with consecutive addresses; the header carries this sector's own LBA
-                // (psx_cdrom_init_sector, cdrom.c:55-74).  The form-2 EDC does not cover the header.
-                psx_cdrom_sector_t tmp;
-                psx_cdrom_init_sector(&tmp, n, PSX_CDROM_SECTOR_TYPE_MODE2_FORM2);
-                memcpy(dst + 12, (const uint8_t*)&tmp + 12, 3);
-            }
-            audio_sector++;
         }
+    }
+    auto build = [&](int n0, int n1) {
+        uint8_t sector[PSX_CDROM_SECTOR_SIZE];
+        for (int n = n0; n < n1; n++) {
+            uint8_t* dst = out + (size_t)n * ssz;
+            const int frame = sec_frame[(size_t)n], offset = sec_off[(size_t)n];
+            if (frame >= 0) {
+                const int budget = pl.budgets[(size_t)frame];
+                memset(sector, 0, sizeof sector);            // the reference's buffer is an uninitialised stack array
+                // init_sector_buffer_video, filefmt.c:73-91
+                psx_cdrom_sector_xa_subheader_t* sub = nullptr;
+                if (s->format == FORMAT_STRCD) {
+                    psx_cdrom_init_sector((psx_cdrom_sector_t*)sector, n, PSX_CDROM_SECTOR_TYPE_MODE2_FORM1);
+                    sub = ((psx_cdrom_sector_t*)sector)->mode2.subheader;
+                } else if (s->format == FORMAT_STR) {
+                    sub = (psx_cdrom_sector_xa_subheader_t*)sector;
+                }
+                if (sub) {
+                    sub->file = (uint8_t)s->audio_xa_file;
+                    sub->channel = (uint8_t)(s->audio_xa_channel & PSX_CDROM_SECTOR_XA_CHANNEL_MASK);
+                    sub->submode = PSX_CDROM_SECTOR_XA_SUBMODE_DATA | PSX_CDROM_SECTOR_XA_SUBMODE_RT;
+                    sub->coding = 0;
+                    sub[1] = sub[0];
+                }
+                // the 32-byte chunk header + 2016 payload bytes of encode_sector_str, mdec.c:782-832
+                const uint8_t* fo = bs.data() + (size_t)frame * ostride;
+                uint8_t* hd = sector + at;
+                put_le16(hd + 0x00, 0x0160);
+                put_le16(hd + 0x02, (unsigned)s->str_video_id);
+                put_le16(hd + 0x04, (unsigned)(offset / 2016));
+                put_le16(hd + 0x06, (unsigned)(budget / 2016));
+                put_le32(hd + 0x08, (unsigned)(frame + 1));                         // frame_index counts from 1
+                put_le32(hd + 0x0C, (unsigned)res[(size_t)frame].bytes_used);
+                put_le16(hd + 0x10, (unsigned)s->video_width);
+                put_le16(hd + 0x12, (unsigned)s->video_height);
+                memcpy(hd + 0x14, fo, 8);
+                put_le32(hd + 0x1C, 0);
+                memcpy(hd + 0x20, fo + offset, 2016);
+                psx_cdrom_calculate_checksums((psx_cdrom_sector_t*)sector, PSX_CDROM_SECTOR_TYPE_MODE2_FORM1);
+                memcpy(dst, sector, ssz);
+            } else {
+                memcpy(dst, xa_out.data() + (size_t)offset * ssz, ssz);
+                if (s->format == FORMAT_STRCD) {
+                    // the audio sectors were assembled with consecutive addresses; the header carries this sector's own LBA
+                    // (psx_cdrom_init_sector, cdrom.c:55-74).  The form-2 EDC does not cover the header.
+                    psx_cdrom_sector_t tmp;
+                    psx_cdrom_init_sector(&tmp, n, PSX_CDROM_SECTOR_TYPE_MODE2_FORM2);
+                    memcpy(dst + 12, (const uint8_t*)&tmp + 12, 3);
+                }
+            }
+        }
+    };
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        int nt = ns >= 2048 ? (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1)) : 1;
+        std::vector<std::thread> th;
+        const int per = (ns + nt - 1) / nt;
+        for (int t = 1; t < nt; t++)
+            if (t * per < ns) th.emplace_back(build, t * per, (t + 1) * per < ns ? (t + 1) * per : ns);
+        build(0, per < ns ? per : ns);
+        for (auto& x : th) x.join();
     }
     pl.pub.quant_scale_sum = qsum;
     if (plan_out) *plan_out = pl.pub;
