@@ -360,3 +360,38 @@ def test_spu_file_framing_vs_reference_golden():
     got = spufile.encode(spufile.settings(spufile.FORMAT_SPU), sine)
     assert got.size == 12672 and got[16:20].tolist() == [0x24, 0x00, 0x70, 0x13]
     assert np.array_equal(got, gold["config_spu_sine"])
+
+
+def test_spu_strided_input_is_not_read_past_its_last_sample():
+    """the reference reads samples[i * pitch] for i < n (adpcm.c:65,110): with `samples + channel` and pitch = channels the
+    caller's buffer ends (n - 1) * pitch + 1 elements after the pointer.  Put that end on a page boundary with an
+    inaccessible page behind it: the host path must not touch it, and the output must equal the contiguous encode."""
+    import ctypes as C
+    import mmap
+    from psxavenc_amd import _lib
+    L = _lib.lib()
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    n, pitch = 28 * 40, 2
+    need = ((n - 1) * pitch + 1) * 2                      # bytes the reference may read from `samples + 1`
+    m = mmap.mmap(-1, 4 * page)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(base + 3 * page, page, 0) == 0  # PROT_NONE behind the data
+    start = base + 3 * page - need                        # the strided view ends exactly at the page boundary
+    mono = O.synth_pcm(17, 0, 0, n, 0)
+    view = (C.c_int16 * ((n - 1) * pitch + 1)).from_address(start)
+    for i in range(n):
+        view[i * pitch] = int(mono[i])
+
+    class Chan(C.Structure):
+        _fields_ = [("qerr", C.c_int), ("mse", C.c_uint64), ("prev1", C.c_int), ("prev2", C.c_int)]
+    st = Chan()
+    out = np.zeros(n // 28 * 16, np.uint8)
+    L.psx_audio_spu_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    ln = L.psx_audio_spu_encode(C.byref(st), start, n, pitch, out.ctypes.data)
+    want, _ = O.spu_encode(mono)
+    assert ln == want.size and np.array_equal(out, want)
+    libc.mprotect(base + 3 * page, page, 3)
+    del view
+    m.close()
