@@ -197,6 +197,10 @@ struct Lds {
     uint32_t* ac_code;      // [BS_LUT_SIZE] bits << 24 | deficit << 17 | code
     uint8_t* dc_plen;       // [16]
     uint8_t* dc_prefix;     // [16]
+    uint8_t* qzz;           // [64] quant matrix in scan order
+    uint4* tab_sel;         // [64] per lane: v_perm selectors of the pixel gather (PixelLane::sel)
+    uint4* tab_pix;         // [64] per lane: pixel row offset, second-half offset, bytes per macroblock row, -
+    uint4* tab_z;           // [64] per lane: zig-zag scatter addresses, two per dword
     int16_t* tiles;         // per-wave DCT staging / code list
     int* scalars;           // [S_COUNT]
 };
@@ -221,6 +225,7 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_word
     b += BS_LUT_SIZE * 4;         // ac_code
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
+    b += 3 * 64 * 16 + 64;        // per-lane constant tables, quant matrix
     b += (size_t)waves * kWaveTileBytes;
     b += (size_t)S_COUNT * 4;
     return (b + 15) & ~(size_t)15;
@@ -239,6 +244,10 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
+    L.tab_sel = (uint4*)(base + b);       b += 64 * 16;
+    L.tab_pix = (uint4*)(base + b);       b += 64 * 16;
+    L.tab_z = (uint4*)(base + b);         b += 64 * 16;
+    L.qzz = (uint8_t*)(base + b);         b += 64;
     L.tiles = (int16_t*)(base + b);       b += (size_t)waves * kWaveTileBytes;
     L.scalars = (int*)(base + b);
     return L;
@@ -463,7 +472,9 @@ __device__ __forceinline__ void scan_stepfn(StepFn& f, int lane) {
 // flight per CU.  The hot path is latency-bound (LDS look-ups, DPP scans, ballots), so it is written
 // as short per-block bodies that rely on wave interleaving rather than on wide unrolled bodies.
 // ---------------------------------------------------------------------------------------------
-template <int CODEC, int WAVES, int OCC>
+// STATS: the diagnostics instantiation (pass counters, per-group trace, per-phase clocks; PSXHIP_MDEC_STATS=1).  The production
+// instantiation carries none of it -- not even the branches.
+template <int CODEC, int WAVES, int OCC, bool STATS>
 __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(const FrameJob job) {
     constexpr int kWavesPerGroup = WAVES;
     constexpr int kThreads = WAVES * 64;
@@ -487,33 +498,35 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         L.dc_plen[tid] = c_dc_plen[tid >> 3][tid & 7];
         L.dc_prefix[tid] = c_dc_prefix[tid >> 3][tid & 7];
     }
-    LaneConst lc;
-    lc.quant = c_quant_zz[lane];
-    lc.below = (1ull << lane) - 1ull;
-    lc.lane_m64 = lane - 64;
-
     int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
     int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
     uint32_t* clist = (uint32_t*)tileT;                                // code list of a macroblock (aliases both tiles)
 
-    // inverse zig-zag for the column-pass scatter: this lane handles column (lane & 7) of block (lane >> 3);
-    // the eight LDS byte addresses (relative to the wave's zig-zag tile) are packed two per register
-    uint32_t zaddr[4];
+    // Per-lane constants of the gather and of the column-pass scatter (this lane handles column (lane & 7) of block
+    // (lane >> 3): eight LDS byte addresses relative to the wave's zig-zag tile, packed two per register).  They are the
+    // same for every wavefront and every frame, and eleven registers each lane would otherwise carry -- or spill to scratch
+    // -- for the whole kernel; they live in LDS tables and are read where they are used.
     {
         uint8_t* inv = (uint8_t*)L.tiles;   // temporary use before the tiles are live
         if (tid < 64) inv[c_zagzig[tid]] = (uint8_t)tid;
         __syncthreads();
-        const int zb = (lane >> 3) * kZStride;
+        if (tid < 64) {
+            L.qzz[tid] = c_quant_zz[tid];
+            const PixelLane p = pixel_lane(tid, W, H);
+            L.tab_sel[tid] = make_uint4(p.sel[0], p.sel[1], p.sel[2], p.sel[3]);
+            L.tab_pix[tid] = make_uint4(p.lane_off, p.hi_off, p.mb_row_step, 0u);
+            const int zb = (tid >> 3) * kZStride;
+            uint32_t z[4];
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const uint32_t a0 = (uint32_t)(zb + inv[(2 * v) * 8 + (lane & 7)]) * 2u;
-            const uint32_t a1 = (uint32_t)(zb + inv[(2 * v + 1) * 8 + (lane & 7)]) * 2u;
-            zaddr[v] = a0 | (a1 << 16);
+            for (int v = 0; v < 4; v++) {
+                const uint32_t a0 = (uint32_t)(zb + inv[(2 * v) * 8 + (tid & 7)]) * 2u;
+                const uint32_t a1 = (uint32_t)(zb + inv[(2 * v + 1) * 8 + (tid & 7)]) * 2u;
+                z[v] = a0 | (a1 << 16);
+            }
+            L.tab_z[tid] = make_uint4(z[0], z[1], z[2], z[3]);
         }
         __syncthreads();
     }
-    const PixelLane pl = pixel_lane(lane, W, H);
-    const int blk = lane >> 3, r8 = lane & 7;
 
     // Two groups share a CU in the small shape.  The SIMD arbiter serves the OLDER wavefront first (priority, then age),
     // so left alone the group that arrived first runs at full speed and its partner on the leftovers -- and the partner
@@ -524,14 +537,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     if (tid == 0) { L.scalars[S_HINT] = 0; L.scalars[S_SHARED_HINT] = (int)job.ticket[2]; }
     unsigned long long t_start = 0, t_mark = 0;
     auto mark = [&](int phase) {       // diagnostics: time since the previous mark goes to `phase`
-        if (job.stats && tid == 0) {
+        if (STATS && tid == 0) {
             const unsigned long long now = wall_clock64();
             atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + phase], now - t_mark);
             t_mark = now;
         }
     };
     int n_done = 0;
-    if (job.stats) t_start = t_mark = wall_clock64();
+    if (STATS) t_start = t_mark = wall_clock64();
     unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
     if (tid == 0) next_ticket = atomicAdd(&job.ticket[0], 1u);
     for (;;) {
@@ -544,6 +557,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const int f = L.scalars[S_FRAME];
         if (f >= job.n_frames) break;
 
+        // thread- and lane-derived values (loop bases, masks, LDS addresses) are re-derived per frame from an opaque copy of
+        // the thread index: hoisted out of the frame loop they would be spilled to scratch once per wavefront (4 KB each,
+        // 25 MB per 1000 frames at two frames per group)
+        int tid_f = tid;
+        asm volatile("" : "+v"(tid_f));
+        const int tid = tid_f;               // shadows the kernel-scope copies on purpose
+        const int lane = tid & 63;
+        const int blk = lane >> 3, r8 = lane & 7;
+        LaneConst lc;
+        lc.quant = L.qzz[lane];
+        lc.below = (1ull << lane) - 1ull;
+        lc.lane_m64 = lane - 64;
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
         int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
         // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
@@ -722,16 +747,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
 
         auto fetch = [&](int fx, int fy) {
-            const uint8_t* p = frame + (pl.lane_off + (uint32_t)fy * pl.mb_row_step + (uint32_t)fx * 16u);
+            const uint4 tp = L.tab_pix[lane];
+            const uint8_t* p = frame + (tp.x + (uint32_t)fy * tp.z + (uint32_t)fx * 16u);
             plo = *(const uint2*)p;
-            phi = *(const uint2*)(p + pl.hi_off);
+            phi = *(const uint2*)(p + tp.y);
         };
         // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
         auto dct_mb = [&](bool have_next, int next_fx, int next_fy) {
-            const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[0]);
-            const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, pl.sel[1]);
-            const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, pl.sel[2]);
-            const uint32_t R1 = __builtin_amdgcn_perm(phi.x, plo.y, pl.sel[3]);
+            const uint4 ts = L.tab_sel[lane];
+            const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
+            const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, ts.y);
+            const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, ts.z);
+            const uint32_t R1 = __builtin_amdgcn_perm(phi.x, plo.y, ts.w);
             if (have_next) fetch(next_fx, next_fy);
             int d[8];
             if (lane < 48) {
@@ -750,6 +777,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 //    pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated as an AC coefficient.
                 if (r8 == 0) d[0] = CODEC == 0 ? quant_dc(d[0]) : 0;
                 char* zb = (char*)tileZ;
+                const uint4 tz = L.tab_z[lane];
+                const uint32_t zaddr[4] = {tz.x, tz.y, tz.z, tz.w};
 #pragma unroll
                 for (int v = 0; v < 8; v++) {
                     const uint32_t a = (v & 1) ? (zaddr[v >> 1] >> 16) : (zaddr[v >> 1] & 0xFFFFu);
@@ -1206,7 +1235,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         n_done++;
         mark(3);   // passes
-        if (job.stats && tid == 0) {
+        if (STATS && tid == 0) {
             atomicAdd(&job.stats[0], 1ull);
             atomicAdd(&job.stats[1], (unsigned long long)n_pass);
             atomicAdd(&job.stats[2 + (n_pass > 5 ? 5 : n_pass)], 1ull);
@@ -1315,7 +1344,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         mark(5);   // header + write-out
     }
 
-    if (job.stats && tid == 0 && blockIdx.x < PSXHIP_MDEC_TRACE_GROUPS) {
+    if (STATS && tid == 0 && blockIdx.x < PSXHIP_MDEC_TRACE_GROUPS) {
         unsigned long long* t = job.stats + PSXHIP_MDEC_STATS + 4 * blockIdx.x;
         t[0] = t_start;
         t[1] = wall_clock64();
@@ -1443,8 +1472,13 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     hipStream_t st = (hipStream_t)a->stream;
 #define PSX_LAUNCH(CODEC)                                                                                             \
     do {                                                                                                              \
-        if (a->large) hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge>), grid, block, lds, st, job); \
-        else hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall>), grid, block, lds, st, job);          \
+        if (job.stats) {                                                                                              \
+            if (a->large) hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge, true>), grid, block, lds, st, job); \
+            else hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall, true>), grid, block, lds, st, job);          \
+        } else {                                                                                                      \
+            if (a->large) hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge, false>), grid, block, lds, st, job); \
+            else hipLaunchKernelGGL((mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall, false>), grid, block, lds, st, job);          \
+        }                                                                                                             \
     } while (0)
     switch (a->codec) {
     case 0: PSX_LAUNCH(0); break;
@@ -1459,10 +1493,16 @@ extern "C" hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes) {
     hipError_t e = hipSuccess;
 #define PSX_ATTR(CODEC)                                                                                                         \
     do {                                                                                                                        \
-        e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall>,                           \
+        e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall, false>,                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                        \
         if (e == hipSuccess)                                                                                                    \
-            e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge>,                       \
+            e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge, false>,                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                    \
+        if (e == hipSuccess)                                                                                                    \
+            e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesSmall, kOccSmall, true>,                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                    \
+        if (e == hipSuccess)                                                                                                    \
+            e = hipFuncSetAttribute((const void*)mdec_encode_frames_kernel<CODEC, kWavesLarge, kOccLarge, true>,                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                                    \
     } while (0)
     switch (codec) {
