@@ -50,8 +50,8 @@ typedef struct psxhip_mdec_ctx psxhip_mdec_ctx_t;
 /* codec: 0 = BS v2, 1 = v3, 2 = v3dc (bs_codec_t, psxavenc/args.h:61-65).
  * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 each.
  * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging).
- * A frame's working set (2 x budget + ~30 bytes per macroblock + ~37 KiB) must fit the CU's 160 KiB LDS, else
- * PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to 44 228-byte budgets;
+ * A frame's working set (budget + min(budget, 8 KiB) + ~30 bytes per macroblock + ~37 KiB) must fit the CU's 160 KiB
+ * LDS, else PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to 77 068-byte budgets;
  * psxhip_mdec_query_geometry() tells before creating a context. */
 int psxhip_mdec_create(psxhip_mdec_ctx_t **ctx, int device, int codec, int width, int height,
                        int max_frame_size);
@@ -87,9 +87,9 @@ int psxhip_mdec_fdct_host(int device, const int16_t *blocks, int n_blocks, int16
 const char *psxhip_mdec_kernel_name(void);
 
 /* What a geometry costs, before creating a context for it.  A frame's working set lives in the CU's
- * 160 KiB LDS: about 2 * max_frame_size + 28 bytes per macroblock + ~37 KiB (two workgroups per CU when twice
- * that fits, else one).  fits == 0 means psxhip_mdec_create would return PSXHIP_EINVAL; max_frame_size_limit
- * is the largest budget this frame size supports (320x240: 56 716 bytes, 640x480: 45 244, 640x512: 44 228). */
+ * 160 KiB LDS: the macroblock staging area (max_frame_size) + the frame image (whole, or one 8 KiB tile at a time when
+ * that is what fits) + ~30 bytes per macroblock + ~37 KiB (two workgroups per CU when twice that fits, else one).  fits == 0 means psxhip_mdec_create would return PSXHIP_EINVAL; max_frame_size_limit
+ * is the largest budget this frame size supports (320x240: 102 044 bytes, 640x480: 79 100, 640x512: 77 068). */
 typedef struct {
 	int32_t fits;
 	int32_t groups_per_cu;          /* frames in flight per compute unit (2 or 1) */

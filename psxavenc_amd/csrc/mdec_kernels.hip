@@ -44,6 +44,7 @@ constexpr int kWavesLarge = 16, kOccLarge = 4;
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
 constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
 constexpr int kPilotMax = 4;      // scales evaluated per pilot round
+constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
 
 __constant__ uint16_t c_ac_len16[BS_LUT_SIZE];
 __constant__ uint32_t c_ac_code[BS_LUT_SIZE];
@@ -62,7 +63,9 @@ struct FrameJob {
     uint8_t* out;
     size_t out_stride;
     psxhip_mdec_result_t* results;
-    int out_words;           // LDS dwords reserved for one frame's output
+    int out_words;           // LDS dwords reserved for the frame image tile (out_tile + 2)
+    int out_tile;            // dwords of the frame image assembled in LDS at a time
+    int max_frame_size;      // the context's largest budget
     int stg_words;           // LDS dwords of the macroblock staging area
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see PassCursor
@@ -100,7 +103,8 @@ enum {
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
-    S_COUNT = S_PILOT_BITS0 + kPilotMax
+    S_TILE_FIRST0 = S_PILOT_BITS0 + kPilotMax,    // [kMaxTiles + 1] first macroblock whose stream starts in image tile t (see the merge)
+    S_COUNT = S_TILE_FIRST0 + kMaxTiles + 1
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -482,7 +486,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const Lds L = carve(smem, job.nmb, job.out_words, job.stg_words, WAVES);
 
     const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
     const int nblk = nmb * 6;
@@ -573,15 +576,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
         // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
         // the output row)] is treated as "nothing fits" (result quant_scale 64, no bytes written)
-        const bool bad_budget = max_size < 8 || max_size > (job.out_words - 2) * 4 || (size_t)max_size > job.out_stride;
+        const bool bad_budget = max_size < 8 || max_size > job.max_frame_size || (size_t)max_size > job.out_stride;
         if (bad_budget) max_size = 8;
-        const int max_words = (max_size + 3) >> 2;
         // fits <=> 8 + 2*ceil(bits/16) <= max_size <=> bits <= 16 * floor((max_size - 8) / 2)   (mdec.c:321-333 in closed form)
         const int limit_bits = 16 * ((max_size - 8) >> 1);
 
         mark(0);   // ticket + idle
         // ---- reset per-frame state
-        for (int i = tid; i < max_words; i += kThreads) L.out[i] = 0u;
+        for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
         if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
         __syncthreads();
@@ -1266,12 +1268,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // Bit offsets of the macroblocks: exclusive scan in encode order (wave 0)
         // =====================================================================================
         if (wid == 0) {
+            // ... and, for images of several tiles, the first macroblock that STARTS in each tile (streams are in encode
+            // order, a macroblock's stream is shorter than a tile): tile t is then fed by macroblocks
+            // [tile_first[t] - 1, tile_first[t + 1]) -- the one before may straddle into it
+            if (lane <= kMaxTiles) L.scalars[S_TILE_FIRST0 + lane] = nmb;
             uint32_t carry = 0;
+            int prev_tile = -1;
             for (int base = 0; base < nmb; base += 64) {
                 const int mbe = base + lane;
                 const int bits = mbe < nmb ? (int)(L.rec[mbe] >> 16) : 0;
                 const int incl = wave::inclusive_scan_add(bits);
-                if (mbe < nmb) L.mb_off[mbe] = carry + (uint32_t)(incl - bits);
+                const uint32_t D = carry + (uint32_t)(incl - bits);
+                if (mbe < nmb) L.mb_off[mbe] = D;
+                int tile = mbe < nmb ? (int)((2u + (D >> 5)) / (uint32_t)job.out_tile) : 0x7FFF;
+                const int before = __builtin_amdgcn_update_dpp(prev_tile, tile, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                if (mbe < nmb && tile != before && tile <= kMaxTiles) L.scalars[S_TILE_FIRST0 + tile] = mbe;
+                prev_tile = __builtin_amdgcn_readlane(tile, 63);
                 carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
             }
         }
@@ -1282,65 +1294,97 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // Output dword j of a macroblock at bit offset D = 32 w + sh receives  stg[j-1] << (32 - sh) | stg[j] >> sh
         // (one v_alignbit); neighbouring macroblocks meet inside a dword, hence ds_or.
         // =====================================================================================
-        {
-            uint32_t* stream = L.out + 2;                  // bitstream starts at byte 8 (mdec.c:686)
-            // four macroblocks per wavefront, 16 lanes each (a macroblock's stream is typically 6..16 dwords)
-            const int j0 = lane & 15;
-            for (int base = wid * 4; base < nmb; base += kWavesPerGroup * 4) {
-                const int mbe = base + (lane >> 4);
-                const bool valid = mbe < nmb;
-                const uint32_t r = valid ? L.rec[mbe] : 0u;
-                const int off = (int)(r & 0xFFFFu), ndw = valid ? (int)(((r >> 16) + 31u) >> 5) : -1;
-                const uint32_t D = valid ? L.mb_off[mbe] : 0u;
-                const uint32_t w0 = D >> 5, sh = D & 31u;
-                for (int j = j0; wave::ballot(j <= ndw) != 0; j += 16) {
-                    const uint32_t cur = j < ndw ? L.stg[off + j] : 0u;
-                    const uint32_t prv = (j >= 1 && j <= ndw) ? L.stg[off + j - 1] : 0u;
-                    const uint32_t v = __builtin_amdgcn_alignbit(prv, cur, sh);
-                    if (v) atomicOr(&stream[w0 + (uint32_t)j], v);
+        // The frame image (8-byte header + bitstream, one dword per 4 output bytes) is assembled in LDS one TILE of
+        // out_tile dwords at a time -- one tile for every budget up to 8 KiB -- so that the LDS need does not grow with
+        // the budget twice (staging + image).
+        const int total_bits = L.scalars[S_TOTAL_BITS];
+        const int image_words = (max_size + 3) >> 2;          // dwords of the output row, the last one possibly partial
+        uint32_t* o32 = (uint32_t*)outp;
+        for (int t0 = 0; t0 < image_words; t0 += job.out_tile) {
+            const int t1 = t0 + job.out_tile;
+            if (t0 > 0) {
+                for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
+                __syncthreads();
+            }
+            {
+                // four macroblocks per wavefront, 16 lanes each (a macroblock's stream is typically 6..16 dwords)
+                const int j0 = lane & 15;
+                const int tile = t0 / job.out_tile;
+                int mb_lo = 0, mb_hi = nmb;
+                if (image_words > job.out_tile) {
+                    // tiles without a starting macroblock (behind the end of the stream) keep the sentinel nmb
+                    mb_lo = L.scalars[S_TILE_FIRST0 + tile] - 1;
+                    if (mb_lo < 0) mb_lo = 0;
+                    mb_hi = tile + 1 <= kMaxTiles ? L.scalars[S_TILE_FIRST0 + tile + 1] : nmb;
+                    for (int u = tile + 2; mb_hi == nmb && u <= kMaxTiles; u++) mb_hi = L.scalars[S_TILE_FIRST0 + u];   // (a tile nobody starts in)
+                }
+                for (int base = mb_lo + wid * 4; base < mb_hi; base += kWavesPerGroup * 4) {
+                    const int mbe = base + (lane >> 4);
+                    const bool valid = mbe < mb_hi;
+                    const uint32_t r = valid ? L.rec[mbe] : 0u;
+                    const int off = (int)(r & 0xFFFFu);
+                    int ndw = valid ? (int)(((r >> 16) + 31u) >> 5) : -1;
+                    const uint32_t D = valid ? L.mb_off[mbe] : 0u;
+                    const int g0 = 2 + (int)(D >> 5);             // image dword of this macroblock's first staging dword
+                    const uint32_t sh = D & 31u;
+                    if (g0 + ndw < t0 || g0 >= t1) ndw = -1;      // nothing of it in this tile
+                    for (int j = j0; wave::ballot(j <= ndw) != 0; j += 16) {
+                        const uint32_t cur = j < ndw ? L.stg[off + j] : 0u;
+                        const uint32_t prv = (j >= 1 && j <= ndw) ? L.stg[off + j - 1] : 0u;
+                        const uint32_t v = __builtin_amdgcn_alignbit(prv, cur, sh);
+                        const int g = g0 + j;
+                        if (v && j <= ndw && g >= t0 && g < t1) atomicOr(&L.out[g - t0], v);
+                    }
                 }
             }
-        }
-        __syncthreads();
-
-        mark(4);   // scan + merge
-        // ---- end-of-frame code, header, results (mdec.c:710-754)
-        const int total_bits = L.scalars[S_TOTAL_BITS];
-        if (tid == 0) {
-            put_bits(L.out + 2, (uint32_t)(total_bits - 10), 10, CODEC == 0 ? 0x1FFu : 0x3FFu);   // mdec.c:647-651,710
-            int hwords = L.scalars[S_NNZ] + 2 * nblk + 2;
-            hwords = (hwords + 0x3F) & ~0x3F;
-            const int blocks_used = (hwords + 1) >> 1;
-            int bytes_used = 8 + 2 * ((total_bits + 15) >> 4);
-            bytes_used = (bytes_used + 3) & ~3;
-            // header dwords are stored pre-swizzle like the rest: final dword = rotate16(staging)
-            const uint32_t h0 = ((uint32_t)blocks_used & 0xFFFFu) | (0x3800u << 16);
-            const uint32_t h1 = ((uint32_t)scale & 0xFFFFu) | ((CODEC == 0 ? 2u : 3u) << 16);
-            L.out[0] = (h0 >> 16) | (h0 << 16);
-            L.out[1] = (h1 >> 16) | (h1 << 16);
-            psxhip_mdec_result_t r;
-            r.quant_scale = scale; r.bytes_used = bytes_used; r.blocks_used = blocks_used; r.uncomp_hwords_used = hwords;
-            job.results[f] = r;
-        }
-        __syncthreads();
-
-        // ---- write-out: staging dword holds two MSB-first 16-bit words; each word is stored low byte
-        //      first (mdec.c:321-333), i.e. the output dword is the staging dword rotated by 16.
-        {
-            const int full = max_size >> 2;
-            uint32_t* o32 = (uint32_t*)outp;
-            for (int i = tid; i < full; i += kThreads) {
-                const uint32_t v = L.out[i];
-                o32[i] = (v >> 16) | (v << 16);
+            __syncthreads();
+            if (t0 == 0) mark(4);   // scan + merge
+            // ---- end-of-frame code, header, results (mdec.c:710-754)
+            if (tid == 0) {
+                // end-of-frame code (mdec.c:647-651,710): 10 bits at stream bit total_bits - 10 = image bit 64 + that
+                const uint32_t pos = 64u + (uint32_t)(total_bits - 10);
+                const int w = (int)(pos >> 5);
+                const uint32_t sb = pos & 31u;
+                const uint64_t tt = (uint64_t)(CODEC == 0 ? 0x1FFu : 0x3FFu) << (64 - sb - 10);
+                const uint32_t hi = (uint32_t)(tt >> 32), lo = (uint32_t)tt;
+                if (w >= t0 && w < t1) L.out[w - t0] |= hi;
+                if (lo && w + 1 >= t0 && w + 1 < t1) L.out[w + 1 - t0] |= lo;
+                if (t0 == 0) {
+                    int hwords = L.scalars[S_NNZ] + 2 * nblk + 2;
+                    hwords = (hwords + 0x3F) & ~0x3F;
+                    const int blocks_used = (hwords + 1) >> 1;
+                    int bytes_used = 8 + 2 * ((total_bits + 15) >> 4);
+                    bytes_used = (bytes_used + 3) & ~3;
+                    // header dwords are stored pre-swizzle like the rest: final dword = rotate16(staging)
+                    const uint32_t h0 = ((uint32_t)blocks_used & 0xFFFFu) | (0x3800u << 16);
+                    const uint32_t h1 = ((uint32_t)scale & 0xFFFFu) | ((CODEC == 0 ? 2u : 3u) << 16);
+                    L.out[0] = (h0 >> 16) | (h0 << 16);
+                    L.out[1] = (h1 >> 16) | (h1 << 16);
+                    psxhip_mdec_result_t r;
+                    r.quant_scale = scale; r.bytes_used = bytes_used; r.blocks_used = blocks_used; r.uncomp_hwords_used = hwords;
+                    job.results[f] = r;
+                }
             }
-            const int tail = max_size & 3;
-            if (tid < tail) {
-                const uint32_t v = L.out[full];
-                const uint32_t o = (v >> 16) | (v << 16);
-                outp[full * 4 + tid] = (uint8_t)(o >> (8 * tid));
+            __syncthreads();
+
+            // ---- write-out: staging dword holds two MSB-first 16-bit words; each word is stored low byte
+            //      first (mdec.c:321-333), i.e. the output dword is the staging dword rotated by 16.
+            {
+                const int full = max_size >> 2;                  // whole output dwords
+                const int n = (full < t1 ? full : t1) - t0;      // ... of them in this tile
+                for (int i = tid; i < n; i += kThreads) {
+                    const uint32_t v = L.out[i];
+                    o32[t0 + i] = (v >> 16) | (v << 16);
+                }
+                const int tail = max_size & 3;
+                if (tail && full >= t0 && full < t1 && tid < tail) {
+                    const uint32_t v = L.out[full - t0];
+                    const uint32_t o = (v >> 16) | (v << 16);
+                    outp[full * 4 + tid] = (uint8_t)(o >> (8 * tid));
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
         mark(5);   // header + write-out
     }
 
@@ -1460,6 +1504,8 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.out_stride = a->out_stride;
     job.results = a->d_results;
     job.out_words = a->out_words;
+    job.out_tile = a->out_tile;
+    job.max_frame_size = a->max_frame_size;
     job.stg_words = a->stg_words;
     job.ticket = a->d_ticket;
     job.stats = a->d_stats;

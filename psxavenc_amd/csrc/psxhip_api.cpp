@@ -96,11 +96,16 @@ namespace {
 int mdec_geometry(int width, int height, int max_frame_size, size_t lds_cu, int* large, int* out_words, int* stg_words,
                   size_t* lds_bytes) {
     const int nmb = (width / 16) * (height / 16);
-    const int ow = (max_frame_size + 3) / 4 + 2;   // +2: a rejected-size tail never indexes past the staging
-    const int sw = (max_frame_size + 3) / 4 + nmb + 2;
+    const int image = (max_frame_size + 3) / 4;     // dwords of the frame image
+    const int sw = image + nmb + 2;
     if (sw > 0xFFFF) return 0;                      // staging offsets are 16-bit
-    int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow, sw, 0) > lds_cu;
+    // the frame image is assembled in LDS either whole or one 8 KiB tile at a time (+2: tile slack).  Whole is a little
+    // faster (one merge sweep) and is taken whenever it costs neither the fit nor the two-groups-per-CU shape.
+    const int ow_tiled = (image < 2048 ? image : 2048) + 2, ow_whole = image + 2;
+    int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow_tiled, sw, 0) > lds_cu;
     if (const char* e = getenv("PSXHIP_MDEC_LARGE")) { if (atoi(e)) lg = 1; }   // experiments
+    int ow = ow_tiled;
+    if ((lg ? 1 : 2) * psxhip_mdec_lds_bytes(nmb, ow_whole, sw, lg) <= lds_cu) ow = ow_whole;
     const size_t need = psxhip_mdec_lds_bytes(nmb, ow, sw, lg);
     if (large) *large = lg;
     if (out_words) *out_words = ow;
@@ -251,6 +256,8 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.out_stride = out_stride;
     a.d_results = d_results;
     a.out_words = c->out_words;
+    a.out_tile = c->out_words - 2;
+    a.max_frame_size = c->max_frame_size;
     a.stg_words = c->stg_words;
     a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
     a.large = c->large;

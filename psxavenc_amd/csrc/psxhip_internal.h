@@ -7,7 +7,7 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k2.13"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k2.14"
 
 #ifdef __cplusplus
 extern "C" {
@@ -23,7 +23,9 @@ typedef struct {
 	uint8_t *d_out;
 	size_t out_stride;
 	psxhip_mdec_result_t *d_results;
-	int out_words;      /* LDS dwords of the frame image: (max_frame_size + 3) / 4 + 2 */
+	int out_words;      /* LDS dwords of the frame image tile: out_tile + 2 */
+	int out_tile;       /* image dwords assembled in LDS at a time: min((max_frame_size + 3) / 4, 2048) */
+	int max_frame_size; /* the context's largest budget */
 	int stg_words;      /* LDS dwords of the macroblock staging area: (max_frame_size + 3) / 4 + nmb + 2 */
 	int grid;
 	int large;          /* 1: 16-wavefront groups, one per CU (large frames / budgets) */

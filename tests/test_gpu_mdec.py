@@ -378,3 +378,24 @@ def test_device_fdct_matches_oracle_on_200k_blocks():
         O.lib().orc_fdct_islow8(O.ptr(want[i], O.i16p))
     assert np.array_equal(got, want), "first differing block %d" % int(np.nonzero((got != want).any(axis=1))[0][0])
     assert got[4, 0] == 64 * -128 and got[5, 0] == 64 * 127 and not got[4, 1:].any()     # SURVEY 8(c) sanity pins
+
+
+def test_large_budgets_assemble_the_frame_image_in_tiles():
+    """budgets above 8 KiB: the frame image is merged and written out one 8 KiB tile at a time (so the LDS need does not
+    grow with the budget twice); 640x512 (the reference CLI's largest size, args.c:410-421) up to 64 KiB, odd budgets,
+    budgets that end inside a tile, streams that end exactly on a tile boundary region"""
+    rng = np.random.default_rng(31)
+    for (codec, w, h, cap, amps) in ((1, 640, 512, 65536, (2, 30)), (0, 320, 240, 56000, (0, 12, 40)), (2, 640, 480, 70001, (6,))):
+        enc = encoder(codec, w, h, cap)
+        for amp in amps:
+            fr = O.synth_frames(w, h, 3, seed=61 + amp, amp=amp)
+            budgets = np.array([cap, int(rng.integers(8193, cap)), 8192 * int(rng.integers(2, cap // 8192 + 1)) - int(rng.integers(0, 3))], np.int32)
+            budgets = np.minimum(budgets, cap)
+            want, want_res, rc = O.mdec_encode(codec, w, h, fr, budgets, stride=cap)
+            if rc != 0:
+                continue
+            out, res = enc.encode_frames_host(fr, budgets)
+            for k in range(3):
+                assert np.array_equal(out[k, :budgets[k]], want[k, :budgets[k]]), (codec, w, h, amp, k, int(budgets[k]))
+                assert np.array_equal(res[k], want_res[k])
+        enc.close()
