@@ -279,7 +279,8 @@ def _oracle_str_stream(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm
     return stream, ost.quant_scale_sum
 
 
-@pytest.mark.parametrize("fmt,codec,w,h,n_frames,channels", [(7, 0, 320, 240, 160, 2), (6, 1, 160, 112, 40, 1), (9, 2, 96, 64, 30, 0)])
+@pytest.mark.parametrize("fmt,codec,w,h,n_frames,channels", [(7, 0, 320, 240, 160, 2), (6, 1, 160, 112, 40, 1), (9, 2, 96, 64, 30, 0),
+                                                            (7, 0, 320, 240, 240, 2)])     # 2400 sectors: the threaded interleave
 def test_batched_str_mux_whole_stream_vs_oracle_loop(fmt, codec, w, h, n_frames, channels):
     """psxhip_str_encode_host (product code: one batched MDEC launch + one XA stream + host interleave) against the
     reference's sector-by-sector loop restated over the oracle, whole stream, for config 'strcd v2' (160 frames) and the
@@ -301,7 +302,7 @@ def test_batched_str_mux_whole_stream_vs_oracle_loop(fmt, codec, w, h, n_frames,
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
     assert p2.quant_scale_sum == qsum
-    if fmt == 7:
+    if fmt == 7 and n_frames == 160:
         b = strmux.frame_budgets(s, 0, 5).tolist()
         assert b == [16128, 18144, 18144, 18144, 16128]
         import hashlib
