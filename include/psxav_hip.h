@@ -110,10 +110,13 @@ int psxhip_mdec_query_geometry(int device, int codec, int width, int height, int
 /* after those, 4 entries per workgroup (the first PSXHIP_MDEC_TRACE_GROUPS groups of the last launch): start and end
  * time (100 MHz wall clock), frames encoded, reserved */
 #define PSXHIP_MDEC_TRACE_GROUPS 1024
-/* and then 8 per-phase time sums over all groups (100 MHz ticks of each group's first thread): 0 ticket/idle, 1 reset +
- * DC pre-pass, 2 pilot, 3 passes over the frame, 4 offset scan + merge, 5 header + write-out */
+/* and then 16 time sums over all groups (100 MHz ticks).  Of each group's first thread, per phase: 0 ticket/idle, 1 reset +
+ * DC pre-pass, 2 pilot, 3 passes over the frame, 4 offset scan + merge, 5 header + write-out.  Over all wavefronts: 6 time
+ * spent waiting at group barriers, 7 residency; 8..13 the barrier time by barrier (frame start, DC pre-pass + pilot,
+ * checkpoint, end of pass, search step, merge + write-out).  Word 2 of a group's trace record: frames | ticks from group
+ * entry to the end of its prologue << 8 | ticks to the end of its first frame << 32. */
 #define PSXHIP_MDEC_STATS_PHASE0 (PSXHIP_MDEC_STATS + 4 * PSXHIP_MDEC_TRACE_GROUPS)
-#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS_PHASE0 + 8)
+#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS_PHASE0 + 16)
 int psxhip_mdec_read_stats(psxhip_mdec_ctx_t *ctx, unsigned long long *out, int n, int reset);
 
 /* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */

@@ -486,6 +486,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const Lds L = carve(smem, job.nmb, job.out_words, job.stg_words, WAVES);
 
     const int tid = (int)threadIdx.x;
+    unsigned long long t_entry = 0, t_first = 0;
+    if (STATS) t_entry = wall_clock64();
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
     const int nblk = nmb * 6;
@@ -538,25 +540,40 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
     const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
     if (tid == 0) { L.scalars[S_HINT] = 0; L.scalars[S_SHARED_HINT] = (int)job.ticket[2]; }
-    unsigned long long t_start = 0, t_mark = 0;
+    unsigned pass_sum = 0, pass_hist[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_start = 0, t_mark = 0, phase_ticks[6] = {0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {       // diagnostics: time since the previous mark goes to `phase`
         if (STATS && tid == 0) {
             const unsigned long long now = wall_clock64();
-            atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + phase], now - t_mark);
+            phase_ticks[phase] += now - t_mark;      // summed up in registers, added to the global sums when the group leaves
             t_mark = now;
+        }
+    };
+    unsigned long long wait_ticks = 0, wait_cat[6] = {0, 0, 0, 0, 0, 0};
+    auto group_sync = [&](int c) {          // diagnostics: time each wavefront spends waiting at group barriers
+        if (STATS) {
+            const unsigned long long a = wall_clock64();
+            __syncthreads();
+            const unsigned long long w = wall_clock64() - a;
+            wait_ticks += w;
+            wait_cat[c] += w;
+        } else {
+            __syncthreads();
         }
     };
     int n_done = 0;
     if (STATS) t_start = t_mark = wall_clock64();
     unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
-    if (tid == 0) next_ticket = atomicAdd(&job.ticket[0], 1u);
+    // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
+    // hands out the frames after those
+    if (tid == 0) next_ticket = blockIdx.x;
     for (;;) {
         // ---- next frame: tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
         if (tid == 0) {
             L.scalars[S_FRAME] = (int)next_ticket;
-            next_ticket = atomicAdd(&job.ticket[0], 1u);
+            next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
         }
-        __syncthreads();
+        group_sync(0);
         const int f = L.scalars[S_FRAME];
         if (f >= job.n_frames) break;
 
@@ -586,7 +603,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
         if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
-        __syncthreads();
+        group_sync(0);
 
         // =====================================================================================
         // v3 / v3dc: the DC terms come first, because a block's DC code depends on the previous block of the same
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     for (int u = 0; u < kDcItems; u++) item_sums(v[u], ch[u], R[u], c[u], ok[u]);
                 }
             }
-            __syncthreads();
+            group_sync(1);
             // The DPCM chains (mdec.c:454-479): Cr, Cb and Y (4 blocks per macroblock), each in encode order.
             // Element i maps last -> new_last:
             //   dc % 4 != 2 : constant 4*round(dc/4)                (last is always a multiple of 4)
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     scan_stepfn(f, lane);
                     if (lane == 63) { L.dc_fn[4 * q + 0] = f.thr; L.dc_fn[4 * q + 1] = f.lo; L.dc_fn[4 * q + 2] = f.hi; }
                 }
-                __syncthreads();
+                group_sync(1);
                 // (B) wavefront c scans chain c's chunk totals (lanes = chunks)
                 if (wid < 3) {
                     const int q0 = wid == 0 ? 0 : (wid == 1 ? cc : 2 * cc), nq = wid == 2 ? cy : cc;
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         carry = __builtin_amdgcn_readlane(cur, 63);
                     }
                 }
-                __syncthreads();
+                group_sync(1);
                 // (C)
                 int bits = 0;
                 for (int q = wid; q < n_chunks; q += kWavesPerGroup) {
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 bits = wave::reduce_add(bits);
                 if (lane == 0 && bits) atomicAdd(&L.scalars[S_DC_BITS], bits);
             }
-            __syncthreads();
+            group_sync(1);
         }
         mark(1);   // reset + DC pre-pass
         const int dc_bits = CODEC == 0 ? 10 * nblk : L.scalars[S_DC_BITS];
@@ -807,7 +824,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
         if (trust_hint) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
-            __syncthreads();
+            group_sync(1);
         } else {
         float cfp[kPilotPerWave][6];
 #pragma unroll
@@ -847,7 +864,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             L.scalars[S_PILOT_HI] = 64;      // smallest scale estimated to fit
         }
         for (;;) {
-            __syncthreads();
+            group_sync(1);
             const int np = L.scalars[S_PILOT_N];
             if (np == 0) break;
             if (wid * kPilotPerWave < n_pilot) {
@@ -861,7 +878,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (lane == 0) atomicAdd(&L.scalars[S_PILOT_BITS0 + j], t);
                 }
             }
-            __syncthreads();
+            group_sync(1);
             if (tid == 0) {
                 int p_lo = L.scalars[S_PILOT_LO], p_hi = L.scalars[S_PILOT_HI];
                 for (int j = 0; j < np; j++) {
@@ -919,7 +936,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             L.scalars[S_DONE] = np.done;
             L.scalars[S_RESULT] = st.best;
         }
-        __syncthreads();
+        group_sync(1);
 
         int n_pass = 0;
         while (!L.scalars[S_DONE]) {
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // a further emitting pass rebuilds the staging area
                 for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
                 if (tid == 0) { L.scalars[S_STG_NEXT] = 0; L.scalars[S_OVERFLOW] = 0; }
-                __syncthreads();
+                group_sync(5);
             }
             PassCursor cur = pass_cursor(wid, kWavesPerGroup, job.trips, job.it_step, nx);
             bool cur_valid = cur.m < nmb;
@@ -972,7 +989,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             for (int it = 0; it < job.trips; it++) {
                 if (it == check_it) {
                     flush();
-                    __syncthreads();
+                    group_sync(2);
                     if (tid == 0) {
                         const int done = L.scalars[S_CK_DONE];
                         long long pa = 0, pb = 0;
@@ -982,7 +999,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         L.scalars[S_ABORT] = g;
                         if (g) L.scalars[S_ABORTS_LEFT] = L.scalars[S_ABORTS_LEFT] - 1;
                     }
-                    __syncthreads();
+                    group_sync(2);
                     if (L.scalars[S_ABORT]) { aborted = true; break; }
                 }
                 if (WAVES == kWavesSmall) {
@@ -1060,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      as two extra leading bits of the NEXT block's DC code; the macroblock's last one is appended by
                     //      stage_alloc().
                     int kcarry_a = 0, kcarry_b = 0, bcarry = 0;
-                    auto chunk = [&](int base, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16) {
+                    auto chunk = [&](int base, bool low, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16) {
                         const int i = base + lane;
                         const bool live = i < count;
                         const uint32_t e = live ? clist[i] : (63u << 17);      // dead lanes: |n| = 0 at scan position 63
@@ -1075,7 +1092,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         QuantK ek;
                         ek.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, ke.inv)));
                         ek.bias = __builtin_fmaf(0.25f, ek.inv, 0.5f);
-                        if (list_low) {
+                        if (low) {
                             const int ka = __builtin_amdgcn_update_dpp(kcarry_a, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
                             if (do_count) {
                                 QuantK ck;
@@ -1087,7 +1104,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             kcarry_a = __builtin_amdgcn_readlane(k, 63);
                         }
                         int q = quant_mag(magf, ek);                           // <= 2048
-                        if (list_low) {
+                        if (low) {
                             // previous surviving entry
                             const uint64_t sm = wave::ballot(q != 0 || is_dc);
                             const uint64_t below = sm & lc.below;
@@ -1148,10 +1165,44 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         emit_bits += (int)mb_bits;
                         return (uint32_t)off * 32u;
                     };
+                    bool low = list_low;
+                    if (low && count > 64) {
+                        // A long list at the count scale (busy macroblocks, fine scales): count its codes chunk by chunk and keep
+                        // only the entries that are still non-zero at the emit scale -- typically fewer than half.  They are
+                        // compacted in place (a survivor's slot is never behind its own entry, and a wavefront's LDS accesses
+                        // complete in order); what follows then sees a list made at the emit scale.
+                        int sc = 0, kcarry = 0;
+                        for (int base = 0; base < count; base += 64) {
+                            const int i = base + lane;
+                            const bool live = i < count;
+                            const uint32_t e = live ? clist[i] : (63u << 17);
+                            const int k = (int)((e >> 17) & 63u);
+                            const bool is_dc = k == 0;
+                            const bool is_ac = live && !is_dc;
+                            const float magf = (float)(e & 0xFFFFu);
+                            QuantK ck, ek;
+                            ck.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, kc.inv)));
+                            ck.bias = __builtin_fmaf(0.25f, ck.inv, 0.5f);
+                            ek.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, ke.inv)));
+                            ek.bias = __builtin_fmaf(0.25f, ek.inv, 0.5f);
+                            const int ka = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+                            kcarry = __builtin_amdgcn_readlane(k, 63);
+                            const int qa = quant_mag(magf, ck);
+                            const int cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
+                            acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
+                            const bool surv = live && (is_dc || quant_mag(magf, ek) != 0);
+                            const uint64_t sm = wave::ballot(surv);
+                            if (surv) clist[sc + wave::popc_below(sm)] = e;
+                            sc += (int)__builtin_popcountll(sm);
+                        }
+                        wave_sync();
+                        count = sc;
+                        low = false;
+                    }
                     if (count <= 64) {
                         int len, deficit, cnt16;
                         uint32_t code;
-                        chunk(0, list_low, len, code, deficit, cnt16);
+                        chunk(0, low, low, len, code, deficit, cnt16);
                         const int incl = wave::inclusive_scan_add(len);
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
                         if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
@@ -1164,7 +1215,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         for (int base = 0; base < count; base += 64) {
                             int len, deficit, cnt16;
                             uint32_t code;
-                            chunk(base, list_low, len, code, deficit, cnt16);
+                            chunk(base, low, low, len, code, deficit, cnt16);
                             lsum += len;
                             acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
                         }
@@ -1175,7 +1226,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         for (int base = 0; base < count; base += 64) {
                             int len, deficit, cnt16;
                             uint32_t code;
-                            chunk(base, false, len, code, deficit, cnt16);
+                            chunk(base, low, false, len, code, deficit, cnt16);
                             const int incl = wave::inclusive_scan_add(len);
                             if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
@@ -1197,7 +1248,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
             }
             if (!aborted) flush();
-            __syncthreads();
+            group_sync(3);
             if (tid == 0) {
                 MdecSearch st = *srch;
                 if (aborted) {
@@ -1233,14 +1284,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
                 }
             }
-            __syncthreads();
+            group_sync(4);
         }
         n_done++;
         mark(3);   // passes
         if (STATS && tid == 0) {
-            atomicAdd(&job.stats[0], 1ull);
-            atomicAdd(&job.stats[1], (unsigned long long)n_pass);
-            atomicAdd(&job.stats[2 + (n_pass > 5 ? 5 : n_pass)], 1ull);
+            pass_sum += (unsigned)n_pass;
+            for (int c = 0; c < 6; c++) pass_hist[c] += (n_pass > 5 ? 5 : n_pass) == c ? 1u : 0u;
         }
 
         const int scale = L.scalars[S_RESULT];
@@ -1260,7 +1310,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 r.quant_scale = 64; r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
                 job.results[f] = r;
             }
-            __syncthreads();
+            group_sync(5);
             continue;
         }
 
@@ -1287,7 +1337,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
             }
         }
-        __syncthreads();
+        group_sync(5);
 
         // =====================================================================================
         // Merge: macroblock streams (dword-aligned in staging) -> their bit positions in the frame image.
@@ -1304,7 +1354,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             const int t1 = t0 + job.out_tile;
             if (t0 > 0) {
                 for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
-                __syncthreads();
+                group_sync(5);
             }
             {
                 // four macroblocks per wavefront, 16 lanes each (a macroblock's stream is typically 6..16 dwords)
@@ -1337,7 +1387,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                 }
             }
-            __syncthreads();
+            group_sync(5);
             if (t0 == 0) mark(4);   // scan + merge
             // ---- end-of-frame code, header, results (mdec.c:710-754)
             if (tid == 0) {
@@ -1365,7 +1415,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     job.results[f] = r;
                 }
             }
-            __syncthreads();
+            group_sync(5);
 
             // ---- write-out: staging dword holds two MSB-first 16-bit words; each word is stored low byte
             //      first (mdec.c:321-333), i.e. the output dword is the staging dword rotated by 16.
@@ -1383,16 +1433,46 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     outp[full * 4 + tid] = (uint8_t)(o >> (8 * tid));
                 }
             }
-            __syncthreads();
+            group_sync(5);
         }
         mark(5);   // header + write-out
+        if (STATS && n_done == 1) t_first = wall_clock64();
     }
 
+    unsigned long long t_end = 0;
+    if (STATS) t_end = wall_clock64();
+    if (STATS && tid == 0) {
+        atomicAdd(&job.stats[0], (unsigned long long)n_done);
+        atomicAdd(&job.stats[1], (unsigned long long)pass_sum);
+        for (int c = 0; c < 6; c++) {
+            atomicAdd(&job.stats[2 + c], (unsigned long long)pass_hist[c]);
+            atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + c], phase_ticks[c]);
+        }
+    }
+    if (STATS) {
+        // per-wavefront sums -> one set of global atomics per group (thousands of wavefronts adding to the same few words
+        // at the end of the kernel would dominate what is being measured)
+        const unsigned long long t_leave = wall_clock64();
+        __syncthreads();
+        if (tid < 8) L.stg[tid] = 0u;
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            atomicAdd(&L.stg[6], (uint32_t)wait_ticks);
+            atomicAdd(&L.stg[7], (uint32_t)(t_leave - t_entry));
+            for (int c = 0; c < 6; c++) atomicAdd(&L.stg[c], (uint32_t)wait_cat[c]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + 6], (unsigned long long)L.stg[6]);
+            atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + 7], (unsigned long long)L.stg[7]);
+            for (int c = 0; c < 6; c++) atomicAdd(&job.stats[PSXHIP_MDEC_STATS_PHASE0 + 8 + c], (unsigned long long)L.stg[c]);
+        }
+    }
     if (STATS && tid == 0 && blockIdx.x < PSXHIP_MDEC_TRACE_GROUPS) {
         unsigned long long* t = job.stats + PSXHIP_MDEC_STATS + 4 * blockIdx.x;
-        t[0] = t_start;
-        t[1] = wall_clock64();
-        t[2] = (unsigned long long)n_done;
+        t[0] = t_entry;
+        t[1] = t_end;
+        t[2] = (unsigned long long)n_done | ((t_start - t_entry) & 0xFFFFFFull) << 8 | ((t_first ? t_first - t_entry : 0ull) & 0xFFFFFFull) << 32;
         t[3] = (unsigned long long)hw_slot;
     }
     // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are

@@ -43,17 +43,22 @@ def run(name, reps=20):
     print("%-8s %8.4f ms  %10.0f fps  passes/frame %.3f  hist(0,1,2,3,4,5+) %s  scales %s" % (
         name, ms, n / ms * 1e3, s[1] / max(1, s[0]), s[2:8], dict(zip(sc.tolist(), cnt.tolist()))), flush=True)
     if os.environ.get("PROBE_TRACE"):
-        NT = 8 + 4 * 1024 + 8
+        NT = 8 + 4 * 1024 + 16
         t = (C.c_ulonglong * NT)()
         enc.encode_frames_device(d, budget, d_out=out, d_results=res)
         torch.cuda.synchronize()
         L.psxhip_mdec_read_stats(enc._h, t, NT, 1)
         ph = np.array(list(t)[8 + 4096:], dtype=np.float64)
-        print("   phase share %% (ticket/idle, reset+dc, pilot, passes, scan+merge, header+writeout): %s  total %.1f us/group" % (np.round(100 * ph[:6] / ph.sum(), 1).tolist(), ph.sum() / 100.0 / 512))
+        print("   phase share %% (ticket/idle, reset+dc, pilot, passes, scan+merge, header+writeout): %s  total %.1f us/group" % (np.round(100 * ph[:6] / ph[:6].sum(), 1).tolist(), ph[:6].sum() / 100.0 / 512))
+        print("   wavefront time at group barriers: %.1f%% of wavefront residency" % (100.0 * ph[6] / max(1.0, ph[7])))
+        print("   by barrier (ticket+reset, dc+pilot, checkpoint, end of pass, search step, merge+writeout) %% of residency:", np.round(100.0 * ph[8:14] / max(1.0, ph[7]), 1).tolist())
         a = np.array(list(t)[8:8 + 4096], dtype=np.int64).reshape(-1, 4)
         a = a[a[:, 1] > 0]
         t0 = a[:, 0].min()
-        st, en, nf = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]      # microseconds
+        st, en, nf = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2] & 0xFF      # microseconds
+        pro, first = ((a[:, 2] >> 8) & 0xFFFFFF) / 100.0, ((a[:, 2] >> 32) & 0xFFFFFF) / 100.0
+        print("   prologue us: p10 %.1f p50 %.1f p90 %.1f | first frame done (from group entry) us: p10 %.1f p50 %.1f p90 %.1f max %.1f"
+              % (np.percentile(pro, 10), np.percentile(pro, 50), np.percentile(pro, 90), np.percentile(first, 10), np.percentile(first, 50), np.percentile(first, 90), first.max()))
         print("   groups %d  start us: p0 %.1f p50 %.1f p90 %.1f max %.1f | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | frames/group hist %s"
               % (len(a), st.min(), np.percentile(st, 50), np.percentile(st, 90), st.max(), en.min(), np.percentile(en, 10),
                  np.percentile(en, 50), np.percentile(en, 90), en.max(), np.bincount(nf).tolist()))
