@@ -42,7 +42,7 @@ namespace {
 constexpr int kWavesSmall = 12, kOccSmall = 6;
 constexpr int kWavesLarge = 16, kOccLarge = 4;
 constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 blocks land on disjoint LDS banks
-constexpr int kZStride = 66;      // int16 per block in the zig-zag tile (+1 dword: the 6 blocks' scatters hit different banks)
+constexpr int kZStride = 64;      // int16 per block in the coefficient tile: column-pass lane t stores its 8 outputs at bytes 16 t
 constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
 
@@ -112,6 +112,21 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+// the three-address form with the (wave-uniform) coefficient pair in a scalar register: the accumulator operand is not
+// overwritten, so a chain's first product needs no copy of the rounding constant -- one register holds it for all chains.
+// (Left to itself the compiler picks the two-address v_dot2c with a literal, and a v_mov per chain to seed it.)
+__device__ __forceinline__ int dot2_k(uint32_t x, uint32_t k, int acc) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(k), "v"(acc));
+    return r;
+}
+template <int IMM>     // ... seeded with an inline constant (-16..64)
+__device__ __forceinline__ int dot2_ki(uint32_t x, uint32_t k) {
+    static_assert(IMM >= -16 && IMM <= 64, "inline constant");
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(k), "n"(IMM));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
 }
@@ -160,19 +175,27 @@ __device__ __forceinline__ void fdct8_pk(uint32_t P0, uint32_t P1, uint32_t R0, 
     const uint32_t D0 = pk_sub(P0, R0);   // (o3, o2)
     const uint32_t D1 = pk_sub(P1, R1);   // (o1, o0)
 
+    const int rnd = RND;
     if (COLUMN) {
-        d[0] = dot2(S0, pk(1, 1), dot2(S1, pk(1, 1), 8)) >> 4;
-        d[4] = dot2(S0, pk(1, -1), dot2(S1, pk(-1, 1), 8)) >> 4;
+        d[0] = dot2_k(S0, pk(1, 1), dot2_ki<8>(S1, pk(1, 1))) >> 4;
+        d[4] = dot2_k(S0, pk(1, -1), dot2_ki<8>(S1, pk(-1, 1))) >> 4;
     } else {
-        d[0] = dot2(S0, pk(1, 1), dot2(S1, pk(1, 1), -8 * 128)) * 16;
-        d[4] = dot2(S0, pk(1, -1), dot2(S1, pk(-1, 1), 0)) * 16;
+        d[0] = dot2_k(S0, pk(1, 1), dot2_ki<0>(S1, pk(1, 1))) * 16 - 8 * 128 * 16;
+        d[4] = dot2_k(S0, pk(1, -1), dot2_ki<0>(S1, pk(-1, 1))) * 16;
     }
-    d[2] = dot2(S0, pk(A, B), dot2(S1, pk(-B, -A), RND)) >> SH;
-    d[6] = dot2(S0, pk(B, C), dot2(S1, pk(-C, -B), RND)) >> SH;
-    d[7] = dot2(D0, pk(C7_3, C7_2), dot2(D1, pk(C7_1, C7_0), RND)) >> SH;
-    d[5] = dot2(D0, pk(C5_3, C5_2), dot2(D1, pk(C5_1, C5_0), RND)) >> SH;
-    d[3] = dot2(D0, pk(C3_3, C3_2), dot2(D1, pk(C3_1, C3_0), RND)) >> SH;
-    d[1] = dot2(D0, pk(C1_3, C1_2), dot2(D1, pk(C1_1, C1_0), RND)) >> SH;
+    d[2] = dot2_k(S0, pk(A, B), dot2_k(S1, pk(-B, -A), rnd)) >> SH;
+    d[6] = dot2_k(S0, pk(B, C), dot2_k(S1, pk(-C, -B), rnd)) >> SH;
+    d[7] = dot2_k(D0, pk(C7_3, C7_2), dot2_k(D1, pk(C7_1, C7_0), rnd)) >> SH;
+    d[5] = dot2_k(D0, pk(C5_3, C5_2), dot2_k(D1, pk(C5_1, C5_0), rnd)) >> SH;
+    d[3] = dot2_k(D0, pk(C3_3, C3_2), dot2_k(D1, pk(C3_1, C3_0), rnd)) >> SH;
+    d[1] = dot2_k(D0, pk(C1_3, C1_2), dot2_k(D1, pk(C1_1, C1_0), rnd)) >> SH;
+}
+
+// A constant that is only stored (by one thread, once per frame) should be made where it is stored: hoisted out of the
+// frame loop it occupies a register for the whole kernel, and at 80 registers that means a scratch spill.
+__device__ __forceinline__ int in_loop(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 // wave-level ordering point for LDS traffic between lanes of the same wavefront
@@ -203,14 +226,14 @@ struct Lds {
     uint8_t* dc_prefix;     // [16]
     uint8_t* qzz;           // [64] quant matrix in scan order
     uint4* tab_sel;         // [64] per lane: v_perm selectors of the pixel gather (PixelLane::sel)
-    uint4* tab_pix;         // [64] per lane: pixel row offset, second-half offset, bytes per macroblock row, -
-    uint4* tab_z;           // [64] per lane: zig-zag scatter addresses, two per dword
+    uint4* tab_pix;         // [64] per lane: pixel row offset, second-half offset, macroblock row shift, -
+    uint8_t* tab_nat;       // [64] per lane k: where scan position k sits in a block of the coefficient tile (column * 8 + row)
     int16_t* tiles;         // per-wave DCT staging / code list
     int* scalars;           // [S_COUNT]
 };
 
 static_assert(sizeof(MdecSearch) == 56 && (S_SEARCH % 2) == 0, "MdecSearch lives in scalars[S_SEARCH..+14)");
-constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + zig-zag tile
+constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + coefficient tile
 static_assert(kWaveTileBytes >= 384 * 4, "the per-wave code list (384 entries) aliases the tiles");
 
 __host__ __device__ inline int dc_chunks(int nmb) { return 2 * ((nmb + 63) >> 6) + ((4 * nmb + 63) >> 6); }
@@ -229,7 +252,7 @@ __host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_word
     b += BS_LUT_SIZE * 4;         // ac_code
     b += 32;                      // dc tables
     b = (b + 15) & ~(size_t)15;
-    b += 3 * 64 * 16 + 64;        // per-lane constant tables, quant matrix
+    b += 2 * 64 * 16 + 2 * 64;    // per-lane constant tables, scan-position table, quant matrix
     b += (size_t)waves * kWaveTileBytes;
     b += (size_t)S_COUNT * 4;
     return (b + 15) & ~(size_t)15;
@@ -250,7 +273,7 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg
     L.dc_prefix = (uint8_t*)(base + b);   b += 16;                                 b = (b + 15) & ~(size_t)15;
     L.tab_sel = (uint4*)(base + b);       b += 64 * 16;
     L.tab_pix = (uint4*)(base + b);       b += 64 * 16;
-    L.tab_z = (uint4*)(base + b);         b += 64 * 16;
+    L.tab_nat = (uint8_t*)(base + b);     b += 64;
     L.qzz = (uint8_t*)(base + b);         b += 64;
     L.tiles = (int16_t*)(base + b);       b += (size_t)waves * kWaveTileBytes;
     L.scalars = (int*)(base + b);
@@ -261,8 +284,8 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg
 // bitstream.  Staging dword j holds stream bits [32j, 32j+32) with bit 32j in its MSB.
 __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t pos, int len, uint32_t v) {
     const uint32_t w = pos >> 5, sh = pos & 31;
-    const uint64_t t = (uint64_t)v << (64 - sh - len);
-    const uint32_t hi = (uint32_t)(t >> 32), lo = (uint32_t)t;
+    const uint32_t top = v << (32 - len);                              // the code left-aligned (1 <= len <= 32)
+    const uint32_t hi = top >> sh, lo = __builtin_amdgcn_alignbit(top, 0u, sh);   // lo = sh ? top << (32 - sh) : 0
     atomicOr(&words[w], hi);
     if (lo) atomicOr(&words[w + 1], lo);
 }
@@ -272,6 +295,7 @@ struct LaneConst {
     int quant;          // quant matrix entry at this zig-zag position
     uint64_t below;     // mask of lanes below this one
     int lane_m64;       // lane - 64
+    int zsrc;           // where this lane's scan position sits in a block of the coefficient tile
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -410,7 +434,7 @@ __device__ __forceinline__ void mb_advance(MbCursor& c, int nx) {
 struct PixelLane {
     uint32_t lane_off;       // offset of this lane's pixel row inside macroblock (0, 0)
     uint32_t hi_off;         // chroma rows are 16 bytes long: second half
-    uint32_t mb_row_step;    // bytes per macroblock row for this lane's plane
+    uint32_t mb_row_shift;   // bytes per macroblock row for this lane's plane = 8 W << shift
     uint32_t sel[4];         // v_perm selectors building (p0,p1) (p2,p3) (p7,p6) (p5,p4) as int16 pairs
 };
 __device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
@@ -421,7 +445,7 @@ __device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
     else p.lane_off = ((uint32_t)(((blk - 2) >> 1) * 8 + r8)) * (uint32_t)W + (uint32_t)((blk - 2) & 1) * 8u;
     if (lane >= 48) p.lane_off = 0;                 // idle lanes read the frame's first bytes (unused)
     p.hi_off = is_chroma ? 8u : 0u;
-    p.mb_row_step = (is_chroma ? 8u : 16u) * (uint32_t)W;
+    p.mb_row_shift = is_chroma ? 0u : 1u;
     // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte pool {lo: 0..3, hi: 4..7}; 0x0C = 0x00.
     // Pools (see load_pairs): A = {plo.x, plo.y}, B = {plo.y, phi.x}, C = {plo.y, phi.y}.
     //   luma: the row's 8 pixels are plo.x, plo.y.  chroma: 16 bytes plo.x, plo.y, phi.x, phi.y with this
@@ -504,31 +528,20 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         L.dc_prefix[tid] = c_dc_prefix[tid >> 3][tid & 7];
     }
     int16_t* tileT = L.tiles + (size_t)wid * (kWaveTileBytes / 2);    // [6][kTileStride] row-pass output, transposed
-    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] zig-zag ordered coefficients
+    int16_t* tileZ = tileT + 6 * kTileStride;                          // [6][kZStride] coefficients, column-major within a block
     uint32_t* clist = (uint32_t*)tileT;                                // code list of a macroblock (aliases both tiles)
 
-    // Per-lane constants of the gather and of the column-pass scatter (this lane handles column (lane & 7) of block
-    // (lane >> 3): eight LDS byte addresses relative to the wave's zig-zag tile, packed two per register).  They are the
-    // same for every wavefront and every frame, and eleven registers each lane would otherwise carry -- or spill to scratch
-    // -- for the whole kernel; they live in LDS tables and are read where they are used.
+    // Per-lane constants of the pixel gather (seven registers each lane would otherwise carry -- or spill to scratch -- for
+    // the whole kernel) and the scan-order table: the same for every wavefront and every frame, they live in LDS tables and
+    // are read where they are used.
     {
-        uint8_t* inv = (uint8_t*)L.tiles;   // temporary use before the tiles are live
-        if (tid < 64) inv[c_zagzig[tid]] = (uint8_t)tid;
-        __syncthreads();
         if (tid < 64) {
             L.qzz[tid] = c_quant_zz[tid];
             const PixelLane p = pixel_lane(tid, W, H);
             L.tab_sel[tid] = make_uint4(p.sel[0], p.sel[1], p.sel[2], p.sel[3]);
-            L.tab_pix[tid] = make_uint4(p.lane_off, p.hi_off, p.mb_row_step, 0u);
-            const int zb = (tid >> 3) * kZStride;
-            uint32_t z[4];
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const uint32_t a0 = (uint32_t)(zb + inv[(2 * v) * 8 + (tid & 7)]) * 2u;
-                const uint32_t a1 = (uint32_t)(zb + inv[(2 * v + 1) * 8 + (tid & 7)]) * 2u;
-                z[v] = a0 | (a1 << 16);
-            }
-            L.tab_z[tid] = make_uint4(z[0], z[1], z[2], z[3]);
+            L.tab_pix[tid] = make_uint4(p.lane_off, p.hi_off, p.mb_row_shift, 0u);
+            const int raster = (int)c_zagzig[tid];
+            L.tab_nat[tid] = (uint8_t)((raster & 7) * 8 + (raster >> 3));
         }
         __syncthreads();
     }
@@ -566,14 +579,26 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
     // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
     // hands out the frames after those
-    if (tid == 0) next_ticket = blockIdx.x;
-    for (;;) {
-        // ---- next frame: tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
+    if (tid == 0) {
+        L.scalars[S_FRAME] = (int)blockIdx.x;
+        next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
+    }
+    // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
+    // last tile is written out: the barrier that ends a frame is also the one that starts the next.
+    auto end_of_frame = [&](int tid) {
+        for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
+        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
         if (tid == 0) {
+            // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
             L.scalars[S_FRAME] = (int)next_ticket;
             next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
         }
-        group_sync(0);
+    };
+    for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
+    for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
+    if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_SHARED_HINT) L.scalars[tid] = 0;
+    __syncthreads();
+    for (;;) {
         const int f = L.scalars[S_FRAME];
         if (f >= job.n_frames) break;
 
@@ -589,6 +614,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         lc.quant = L.qzz[lane];
         lc.below = (1ull << lane) - 1ull;
         lc.lane_m64 = lane - 64;
+        lc.zsrc = (int)L.tab_nat[lane];
         const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
         int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
         // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
@@ -599,11 +625,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const int limit_bits = 16 * ((max_size - 8) >> 1);
 
         mark(0);   // ticket + idle
-        // ---- reset per-frame state
-        for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
-        for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
-        group_sync(0);
 
         // =====================================================================================
         // v3 / v3dc: the DC terms come first, because a block's DC code depends on the previous block of the same
@@ -766,10 +787,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
 
         auto fetch = [&](int fx, int fy) {
+            // 32-bit offsets from the (wave-uniform) frame pointer; the macroblock row's offset is scalar arithmetic, a lane
+            // only shifts it (a macroblock row is 8 W bytes of chroma, 16 W of luma)
             const uint4 tp = L.tab_pix[lane];
-            const uint8_t* p = frame + (tp.x + (uint32_t)fy * tp.z + (uint32_t)fx * 16u);
-            plo = *(const uint2*)p;
-            phi = *(const uint2*)(p + tp.y);
+            const uint32_t row = (uint32_t)fy * (uint32_t)(8 * W), col = (uint32_t)fx * 16u;
+            const uint32_t o_lo = tp.x + (row << tp.z) + col, o_hi = o_lo + tp.y;
+            plo = *(const uint2*)(frame + o_lo);
+            phi = *(const uint2*)(frame + o_hi);
         };
         // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
         auto dct_mb = [&](bool have_next, int next_fx, int next_fy) {
@@ -795,16 +819,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 //    scan position 0 and travels with the block's DC slot in the code list.  v3: the DC codes come from the
                 //    pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated as an AC coefficient.
                 if (r8 == 0) d[0] = CODEC == 0 ? quant_dc(d[0]) : 0;
-                char* zb = (char*)tileZ;
-                const uint4 tz = L.tab_z[lane];
-                const uint32_t zaddr[4] = {tz.x, tz.y, tz.z, tz.w};
-#pragma unroll
-                for (int v = 0; v < 8; v++) {
-                    const uint32_t a = (v & 1) ? (zaddr[v >> 1] >> 16) : (zaddr[v >> 1] & 0xFFFFu);
-                    *(int16_t*)(zb + a) = (int16_t)d[v];
-                }
+                // the column's 8 outputs (rows 0..7) leave as one 16-byte store; scan order is applied by the readers (LaneConst::zsrc)
+                uint4 o;
+                o.x = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x05040100u);
+                o.y = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x05040100u);
+                o.z = __builtin_amdgcn_perm((uint32_t)d[5], (uint32_t)d[4], 0x05040100u);
+                o.w = __builtin_amdgcn_perm((uint32_t)d[7], (uint32_t)d[6], 0x05040100u);
+                *(uint4*)&tileZ[lane * 8] = o;
             }
-            wave_sync();     // tileZ holds the macroblock's coefficients, lane k <-> scan position k of each block
+            wave_sync();     // tileZ holds the macroblock's coefficients: block b, column c, row r at [b * 64 + c * 8 + r]
         };
 
         // ---- pilot: kPilotPerWave macroblocks per wavefront, spread evenly over the frame in raster order; their AC bits
@@ -835,7 +858,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 fetch(pc.fx, pc.fy);
                 dct_mb(false, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 6; b++) cf[b] = lane == 0 ? 0.0f : (float)(int)tileZ[b * kZStride + lane];
+                for (int b = 0; b < 6; b++) cf[b] = lane == 0 ? 0.0f : (float)(int)tileZ[b * kZStride + lc.zsrc];
                 wave_sync();
             }
 #pragma unroll
@@ -861,7 +884,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_PILOT_SCALE0 + 3] = 8;
             }
             L.scalars[S_PILOT_LO] = 0;       // largest scale estimated not to fit
-            L.scalars[S_PILOT_HI] = 64;      // smallest scale estimated to fit
+            L.scalars[S_PILOT_HI] = in_loop(64);      // smallest scale estimated to fit
         }
         for (;;) {
             group_sync(1);
@@ -924,6 +947,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid == 0) {
             MdecSearch st;
             mdec_search_init(st);
+            st.best = in_loop(st.best);
             MdecPass np;
             if (limit_bits < fixed_bits || bad_budget) {
                 np.done = 1; np.count_scale = 0; np.emit_scale = 0;
@@ -957,6 +981,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             int acc_edef = 0;            // per lane: deficit over the emitted codes
             int n_codes = 0;             // wave-uniform: codes emitted (AC codes + DC slots)
             int emit_bits = 0, mb_done = 0;  // wave-uniform
+            bool dense_prev = false;         // wave-uniform: the previous macroblock's list at the count scale was too long to walk
             // compaction threshold of this lane: smallest |n| that quantises to non-zero at the list's scale
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
             const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
@@ -1023,7 +1048,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
 
                 int ci[6];       // this lane's coefficient (scan position = lane) of each block; lane 0 (the DC slot) holds 0
 #pragma unroll
-                for (int b = 0; b < 6; b++) ci[b] = (int)tileZ[b * kZStride + lane];
+                for (int b = 0; b < 6; b++) ci[b] = (int)tileZ[b * kZStride + lc.zsrc];
                 wave_sync();     // the tiles are free again (the code list aliases them)
 
                 if (!emit_scale) {
@@ -1040,31 +1065,46 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      at every finer one): |n| quantises to non-zero  <=>  2|n| >= d  <=>  |n| >= ceil(d / 2).
                     //      Entry: [15:0] |n|, [16] sign, [22:17] scan position.  Lane 0 (scan position 0) is always kept: it
                     //      marks the block's DC slot, so the list is the macroblock's code sequence DC, AC..., DC, AC...
-                    //      A macroblock that is dense at the count scale (more than two chunks) is listed at the emit scale
-                    //      instead and counted in place (count_mb): walking a long list twice costs more than it saves.
+                    //      A macroblock that is dense at the count scale (a list of more than two chunks) is listed again at the
+                    //      emit scale and counted in place (count_mb): walking a long list costs more than it saves.
                     uint32_t mag[6];
-                    int n_low = 0;
 #pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        mag[b] = (uint32_t)(ci[b] < 0 ? -ci[b] : ci[b]);
-                        n_low += (int)__builtin_popcountll(wave::ballot(mag[b] >= thr_low));
+                    for (int b = 0; b < 6; b++) mag[b] = (uint32_t)(ci[b] < 0 ? -ci[b] : ci[b]);
+                    auto build_list = [&](uint32_t thr) -> int {
+                        int c = 0;                             // wave-uniform
+#pragma unroll
+                        for (int b = 0; b < 6; b++) {
+                            const uint64_t mk = wave::ballot(mag[b] >= thr) | 1ull;
+                            if (mag[b] >= thr || lane == 0)
+                                clist[c + wave::popc_below(mk)] = mag[b] | ((uint32_t)ci[b] & 0x10000u) | lane_tag;
+                            c += (int)__builtin_popcountll(mk);
+                        }
+                        return c;
+                    };
+                    // (built straight away; only after a dense macroblock the next one is sized up first -- busy content comes in runs)
+                    bool dense = false, list_low = false;      // list_low: the list holds the count scale's codes
+                    int count = 0;
+                    if (count_scale && dense_prev) {
+                        int n_low = 0;
+#pragma unroll
+                        for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot(mag[b] >= thr_low));
+                        dense = n_low > 122;
                     }
-                    const bool list_low = count_scale && n_low <= 122;     // the list holds the count scale's codes
-                    if (count_scale && !list_low) {
+                    if (!dense) {
+                        count = build_list(count_scale ? thr_low : thr_emit);
+                        list_low = count_scale != 0;
+                        dense = count_scale && count > 128;
+                    }
+                    dense_prev = dense;
+                    if (dense) {
                         float cff[6];
 #pragma unroll
                         for (int b = 0; b < 6; b++) cff[b] = lane == 0 ? 0.0f : (float)ci[b];
                         const int a = count_mb(cff, kc, lc, L.ac_len16);
                         acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
-                    }
-                    const uint32_t list_thr = list_low ? thr_low : thr_emit;
-                    int count = 0;                             // wave-uniform
-#pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        const uint64_t mk = wave::ballot(mag[b] >= list_thr) | 1ull;
-                        if (mag[b] >= list_thr || lane == 0)
-                            clist[count + wave::popc_below(mk)] = mag[b] | ((uint32_t)ci[b] & 0x10000u) | lane_tag;
-                        count += (int)__builtin_popcountll(mk);
+                        wave_sync();
+                        count = build_list(thr_emit);
+                        list_low = false;
                     }
                     wave_sync();
 
@@ -1077,13 +1117,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      as two extra leading bits of the NEXT block's DC code; the macroblock's last one is appended by
                     //      stage_alloc().
                     int kcarry_a = 0, kcarry_b = 0, bcarry = 0;
-                    auto chunk = [&](int base, bool low, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16) {
+                    auto chunk = [&](int base, bool low, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16, int& ncodes) {
                         const int i = base + lane;
                         const bool live = i < count;
                         const uint32_t e = live ? clist[i] : (63u << 17);      // dead lanes: |n| = 0 at scan position 63
                         const int k = (int)((e >> 17) & 63u);
                         const bool neg = (e & 0x10000u) != 0;
                         const bool is_dc = k == 0;
+                        const uint64_t dcm = wave::ballot(k == 0);        // (taken next to the compare: it folds into it)
                         const bool is_ac = live && !is_dc;
                         const float magf = (float)(e & 0xFFFFu);
                         cnt16 = 0;
@@ -1106,7 +1147,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         int q = quant_mag(magf, ek);                           // <= 2048
                         if (low) {
                             // previous surviving entry
-                            const uint64_t sm = wave::ballot(q != 0 || is_dc);
+                            const uint64_t sm = wave::ballot(q != 0) | dcm;   // (dead lanes: |n| = 0 at position 63)
+                            ncodes = (int)__builtin_popcountll(sm);
                             const uint64_t below = sm & lc.below;
                             const int ps = 63 - __clzll((long long)below);         // -1 when there is none in this chunk
                             const int kp = __builtin_amdgcn_ds_bpermute(ps << 2, k);
@@ -1115,6 +1157,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         } else {
                             kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
                             kcarry_b = __builtin_amdgcn_readlane(k, 63);
+                            ncodes = count - base < 64 ? count - base : 64;      // a list at the emit scale: every entry is a code
                         }
                         const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
                         q = q > lim ? lim : q;
@@ -1136,7 +1179,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             }
                         } else {
                             // v3 DC slots: block index = number of DC slots before this one in the macroblock's list
-                            const uint64_t dcmask = wave::ballot(is_dc);
+                            const uint64_t dcmask = dcm;
                             if (is_dc) {
                                 const int bi = bcarry + wave::popc_below(dcmask);
                                 dc_code<CODEC>((int)L.dcv[mbe * 6 + bi], bi >= 2, L.dc_plen, L.dc_prefix, len, code);
@@ -1190,9 +1233,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             const int qa = quant_mag(magf, ck);
                             const int cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
                             acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
-                            const bool surv = live && (is_dc || quant_mag(magf, ek) != 0);
-                            const uint64_t sm = wave::ballot(surv);
-                            if (surv) clist[sc + wave::popc_below(sm)] = e;
+                            const int qe = quant_mag(magf, ek);
+                            const uint64_t sm = wave::ballot(qe != 0) | wave::ballot(k == 0);      // (dead lanes: |n| = 0 at position 63)
+                            if ((qe != 0) | (k == 0)) clist[sc + wave::popc_below(sm)] = e;
                             sc += (int)__builtin_popcountll(sm);
                         }
                         wave_sync();
@@ -1200,22 +1243,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         low = false;
                     }
                     if (count <= 64) {
-                        int len, deficit, cnt16;
+                        int len, deficit, cnt16, nc;
                         uint32_t code;
-                        chunk(0, low, low, len, code, deficit, cnt16);
+                        chunk(0, low, low, len, code, deficit, cnt16, nc);
                         const int incl = wave::inclusive_scan_add(len);
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
                         if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                         acc_edef += deficit;
                         acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
-                        n_codes += (int)__builtin_popcountll(wave::ballot(len != 0));
+                        n_codes += nc;
                     } else {
                         // longer lists: add up the lengths first (the allocation needs the macroblock's total), then write
                         int lsum = 0;
                         for (int base = 0; base < count; base += 64) {
-                            int len, deficit, cnt16;
+                            int len, deficit, cnt16, nc;
                             uint32_t code;
-                            chunk(base, low, low, len, code, deficit, cnt16);
+                            chunk(base, low, low, len, code, deficit, cnt16, nc);
                             lsum += len;
                             acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
                         }
@@ -1224,14 +1267,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         kcarry_b = 0;
                         bcarry = 0;
                         for (int base = 0; base < count; base += 64) {
-                            int len, deficit, cnt16;
+                            int len, deficit, cnt16, nc;
                             uint32_t code;
-                            chunk(base, low, false, len, code, deficit, cnt16);
+                            chunk(base, low, false, len, code, deficit, cnt16, nc);
                             const int incl = wave::inclusive_scan_add(len);
                             if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                             acc_edef += deficit;
-                            n_codes += (int)__builtin_popcountll(wave::ballot(len != 0));
+                            n_codes += nc;
                         }
                     }
                     wave_sync();   // the list is overwritten by the next macroblock's tiles
@@ -1310,6 +1353,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 r.quant_scale = 64; r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
                 job.results[f] = r;
             }
+            group_sync(5);      // everyone has read the verdict: the scalars may go
+            end_of_frame(tid);
             group_sync(5);
             continue;
         }
@@ -1321,7 +1366,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // ... and, for images of several tiles, the first macroblock that STARTS in each tile (streams are in encode
             // order, a macroblock's stream is shorter than a tile): tile t is then fed by macroblocks
             // [tile_first[t] - 1, tile_first[t + 1]) -- the one before may straddle into it
-            if (lane <= kMaxTiles) L.scalars[S_TILE_FIRST0 + lane] = nmb;
+            if (lane <= kMaxTiles) L.scalars[S_TILE_FIRST0 + lane] = in_loop(nmb);
             uint32_t carry = 0;
             int prev_tile = -1;
             for (int base = 0; base < nmb; base += 64) {
@@ -1352,10 +1397,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         uint32_t* o32 = (uint32_t*)outp;
         for (int t0 = 0; t0 < image_words; t0 += job.out_tile) {
             const int t1 = t0 + job.out_tile;
-            if (t0 > 0) {
-                for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
-                group_sync(5);
-            }
             {
                 // four macroblocks per wavefront, 16 lanes each (a macroblock's stream is typically 6..16 dwords)
                 const int j0 = lane & 15;
@@ -1387,18 +1428,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                 }
             }
-            group_sync(5);
-            if (t0 == 0) mark(4);   // scan + merge
-            // ---- end-of-frame code, header, results (mdec.c:710-754)
-            if (tid == 0) {
+            // ---- end-of-frame code, header, results (mdec.c:710-754): one thread, alongside the merge (the end-of-frame code
+            //      shares its dwords with the last macroblock, hence atomic; nothing else lands on the two header dwords)
+            if (tid == kThreads - 1) {
                 // end-of-frame code (mdec.c:647-651,710): 10 bits at stream bit total_bits - 10 = image bit 64 + that
                 const uint32_t pos = 64u + (uint32_t)(total_bits - 10);
                 const int w = (int)(pos >> 5);
                 const uint32_t sb = pos & 31u;
                 const uint64_t tt = (uint64_t)(CODEC == 0 ? 0x1FFu : 0x3FFu) << (64 - sb - 10);
                 const uint32_t hi = (uint32_t)(tt >> 32), lo = (uint32_t)tt;
-                if (w >= t0 && w < t1) L.out[w - t0] |= hi;
-                if (lo && w + 1 >= t0 && w + 1 < t1) L.out[w + 1 - t0] |= lo;
+                if (w >= t0 && w < t1) atomicOr(&L.out[w - t0], hi);
+                if (lo && w + 1 >= t0 && w + 1 < t1) atomicOr(&L.out[w + 1 - t0], lo);
                 if (t0 == 0) {
                     int hwords = L.scalars[S_NNZ] + 2 * nblk + 2;
                     hwords = (hwords + 0x3F) & ~0x3F;
@@ -1416,22 +1456,27 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
             }
             group_sync(5);
+            if (t0 == 0) mark(4);   // scan + merge + header
 
             // ---- write-out: staging dword holds two MSB-first 16-bit words; each word is stored low byte
             //      first (mdec.c:321-333), i.e. the output dword is the staging dword rotated by 16.
             {
                 const int full = max_size >> 2;                  // whole output dwords
                 const int n = (full < t1 ? full : t1) - t0;      // ... of them in this tile
-                for (int i = tid; i < n; i += kThreads) {
-                    const uint32_t v = L.out[i];
-                    o32[t0 + i] = (v >> 16) | (v << 16);
-                }
                 const int tail = max_size & 3;
                 if (tail && full >= t0 && full < t1 && tid < tail) {
                     const uint32_t v = L.out[full - t0];
                     const uint32_t o = (v >> 16) | (v << 16);
                     outp[full * 4 + tid] = (uint8_t)(o >> (8 * tid));
                 }
+                if (tail) group_sync(5);      // (the tail bytes' dword is read by up to three threads before it is cleared)
+                // ... and the tile is cleared for whatever is assembled in it next, by the thread that read each dword
+                for (int i = tid; i < job.out_tile + 1; i += kThreads) {
+                    const uint32_t v = L.out[i];
+                    if (i < n) o32[t0 + i] = (v >> 16) | (v << 16);
+                    L.out[i] = 0u;
+                }
+                if (t1 >= image_words) end_of_frame(tid);
             }
             group_sync(5);
         }
@@ -1473,7 +1518,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         t[0] = t_entry;
         t[1] = t_end;
         t[2] = (unsigned long long)n_done | ((t_start - t_entry) & 0xFFFFFFull) << 8 | ((t_first ? t_first - t_entry : 0ull) & 0xFFFFFFull) << 32;
-        t[3] = (unsigned long long)hw_slot;
+        // HW_REG_HW_ID (wave slot, SIMD, CU, shader array / engine) | HW_REG_XCC_ID << 32: which piece of the chip ran the group
+        t[3] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) |
+               (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20) << 32;
     }
     // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are
     //      stream-ordered, see psxav_hip.h)

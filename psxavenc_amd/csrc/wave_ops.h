@@ -49,7 +49,8 @@ __device__ __forceinline__ int popc_below(uint64_t mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// (the intrinsic, not __ballot(): it folds into the compare that produced `p` instead of materialising 0 / 1 first)
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 template <typename T>
 __device__ __forceinline__ T broadcast_first(T v) {

@@ -67,7 +67,23 @@ def run(name, reps=20):
         for x in range(8):
             m = (idx % 8) == x
             print("   xcd-slot %d: end mean %.1f max %.1f frames %s" % (x, en[m].mean(), en[m].max(), np.bincount(nf[m], minlength=4).tolist()))
-        slot = a[:, 3]
+        hw = a[:, 3] & 0xFFFFFFFF
+        xcc = (a[:, 3] >> 32) & 0xF
+        slot = hw & 0xF
+        cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+        where = xcc * 1000 + se * 100 + sh * 50 + cu          # one number per CU
+        order = np.argsort(en)
+        print("   slowest 16 groups (xcc, se, sh, cu, slot, end us):", [(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(slot[i]), round(float(en[i]), 1)) for i in order[-16:]])
+        for x in sorted(set(xcc.tolist())):
+            m = xcc == x
+            print("   xcc %d: groups %d  end mean %.1f max %.1f  CUs %d" % (x, m.sum(), en[m].mean(), en[m].max(), len(set(where[m].tolist()))))
+        percu = {}
+        for i in range(len(en)): percu.setdefault(int(where[i]), []).append(float(en[i]))
+        cu_end = np.array([max(v) for v in percu.values()])
+        print("   per-CU end time (max of its groups): CUs %d  p10 %.1f p50 %.1f p90 %.1f max %.1f | groups per CU hist %s"
+              % (len(cu_end), np.percentile(cu_end, 10), np.percentile(cu_end, 50), np.percentile(cu_end, 90), cu_end.max(), np.bincount([len(v) for v in percu.values()]).tolist()))
+        if os.environ.get("PROBE_TRACE_DUMP"):
+            np.save(os.environ["PROBE_TRACE_DUMP"] + "_%s.npy" % name, np.stack([where, slot, st, en, nf], 1))
         for sl in sorted(set(slot.tolist())):
             m = slot == sl
             print("   wave slot %d: groups %d  end mean %.1f  frames %s" % (sl, m.sum(), en[m].mean(), np.bincount(nf[m], minlength=4).tolist()))
