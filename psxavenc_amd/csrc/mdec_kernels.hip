@@ -45,6 +45,7 @@ constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 bl
 constexpr int kZStride = 64;      // int16 per block in the coefficient tile: column-pass lane t stores its 8 outputs at bytes 16 t
 constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
+constexpr uint32_t kNoMb = 0xFFFFu;   // pass order entry without a macroblock (the last round of tickets may be partial)
 
 __constant__ uint16_t c_ac_len16[BS_LUT_SIZE];
 __constant__ uint32_t c_ac_code[BS_LUT_SIZE];
@@ -68,7 +69,8 @@ struct FrameJob {
     int max_frame_size;      // the context's largest budget
     int stg_words;           // LDS dwords of the macroblock staging area
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
-    int it_step;             // iteration visiting stride (coprime with trips), see PassCursor
+    int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
+    const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
     unsigned int* ticket;    // [4]: [2] = last answer | budget << 8 of any group (a hint that survives launches),: next frame to hand out, workgroups finished (self-resetting)
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
@@ -95,6 +97,8 @@ enum {
     S_PILOT_LO,
     S_PILOT_HI,
     S_CK_DONE,          // checkpoint: macroblocks finished so far in this pass
+    S_MB_NEXT,          // pass tickets: next macroblock ticket to hand out
+    S_PAD1,             // (keeps S_SEARCH 8-byte aligned)
     S_ABORT,            // checkpoint verdict: 0 = carry on, else the new guess
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
@@ -380,41 +384,6 @@ __device__ __forceinline__ void dc_code(int v, int luma, const uint8_t* plen, co
 struct MbCursor {
     int fx, fy;
 };
-// Pass order: a pass is `trips` iterations; in iteration `it` the W wavefronts of a group take the W horizontally
-// adjacent macroblocks  row * W + w  (raster order, w = wavefront index) of "iteration row"  row = it * step mod trips.
-// The stride makes every prefix of a pass an even sample of the frame -- the quarter-pass checkpoint projects the
-// frame's bits from it -- while the wavefronts still share cache lines inside an iteration.
-struct PassCursor {
-    int m;          // raster index (>= nmb: nothing to do in this iteration)
-    int fx, fy;
-    int d_m, d_fx, d_fy;     // per-iteration increment  step * W
-    int w_m, w_fx, w_fy;     // wrap-around decrement    trips * W
-};
-__device__ __forceinline__ PassCursor pass_cursor(int wid, int waves, int trips, int step, int nx) {
-    PassCursor c;
-    c.m = wid;
-    c.fy = wid / nx;
-    c.fx = wid - c.fy * nx;
-    c.d_m = step * waves;
-    c.d_fy = c.d_m / nx;
-    c.d_fx = c.d_m - c.d_fy * nx;
-    c.w_m = trips * waves;
-    c.w_fy = c.w_m / nx;
-    c.w_fx = c.w_m - c.w_fy * nx;
-    return c;
-}
-__device__ __forceinline__ void pass_advance(PassCursor& c, int nx) {
-    c.m += c.d_m;
-    c.fx += c.d_fx;
-    c.fy += c.d_fy;
-    if (c.fx >= nx) { c.fx -= nx; c.fy++; }
-    if (c.m >= c.w_m) {
-        c.m -= c.w_m;
-        c.fx -= c.w_fx;
-        c.fy -= c.w_fy;
-        if (c.fx < 0) { c.fx += nx; c.fy--; }
-    }
-}
 __device__ __forceinline__ MbCursor mb_cursor(int raster_index, int nx) {
     MbCursor c;
     c.fy = raster_index / nx;
@@ -959,6 +928,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             L.scalars[S_PASS_EMIT] = np.emit_scale;
             L.scalars[S_DONE] = np.done;
             L.scalars[S_RESULT] = st.best;
+            L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
         }
         group_sync(1);
 
@@ -972,9 +942,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (tid == 0) { L.scalars[S_STG_NEXT] = 0; L.scalars[S_OVERFLOW] = 0; }
                 group_sync(5);
             }
-            PassCursor cur = pass_cursor(wid, kWavesPerGroup, job.trips, job.it_step, nx);
-            bool cur_valid = cur.m < nmb;
-            if (cur_valid) fetch(cur.fx, cur.fy);
+            // Macroblocks are handed out by ticket (an LDS counter): wavefronts that draw cheap macroblocks draw more, and all of
+            // them reach the end of the pass within one macroblock of each other.  Ticket t visits macroblock order[t]; the order
+            // (psxhip_mdec_pass_order) spreads every run of tickets evenly over the frame.  A wavefront's first two tickets are
+            // its own; from then on it draws the ticket after next while it works, so that neither the counter's round trip nor
+            // the order look-up (a scalar load) nor the pixel fetch of the next macroblock is waited for.
+            typedef const uint32_t __attribute__((address_space(4))) * OrderPtr;
+            const OrderPtr order = (OrderPtr)(uintptr_t)job.order;
+            const int n_tickets = job.trips * kWavesPerGroup;
+            int cur_t = wid, nxt_t = wid + kWavesPerGroup;
+            uint32_t cur_o = order[cur_t];
+            uint32_t nxt_o = nxt_t < n_tickets ? order[nxt_t] : kNoMb;
+            if (cur_o != kNoMb) fetch((int)(cur_o & 0xFFu), (int)(cur_o >> 8));
             const QuantK kc = make_quant(lc.quant, count_scale ? count_scale : 1);
             const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
             int acc_cnt = 0;             // per lane: bits | deficit << 16 over this wavefront's macroblocks (count scale)
@@ -1005,14 +984,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (lane == 0) atomicAdd(&L.scalars[S_CK_DONE], mb_done);
                 mb_done = 0;
             };
-            // Checkpoint after a quarter of the pass: the macroblocks done so far are an even sample of the frame (PassCursor);
+            // Checkpoint after a quarter of the pass: the macroblocks done so far are an even sample of the frame (psxhip_mdec_pass_order);
             // if their bits, scaled up, say that this pass's scales cannot be the answer, stop and start over with a better guess
             // instead of finding out at the end.  Projections only steer: nothing they say enters the search state.
-            const int check_it = (job.trips >= 8 && L.scalars[S_ABORTS_LEFT] > 0) ? job.trips >> 2 : -1;
-            bool aborted = false;
+            const int check_t = (job.trips >= 8 && L.scalars[S_ABORTS_LEFT] > 0) ? (job.trips >> 2) * kWavesPerGroup : n_tickets;
+            bool aborted = false, checked = false;
 
-            for (int it = 0; it < job.trips; it++) {
-                if (it == check_it) {
+            for (int it = 0; cur_t < n_tickets; it++) {
+                // (every wavefront gets here exactly once, with its first ticket past the quarter mark: the sums then cover
+                //  exactly the first check_t tickets)
+                if (!checked && cur_t >= check_t) {
+                    checked = true;
                     flush();
                     group_sync(2);
                     if (tid == 0) {
@@ -1031,19 +1013,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if ((prio_bits >> (it & 7)) & 1u) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                PassCursor nxt = cur;
-                pass_advance(nxt, nx);
-                const bool nxt_valid = it + 1 < job.trips && nxt.m < nmb;
-                const int mbe = cur.fx * ny + cur.fy;
-                const bool valid = cur_valid;
-                cur_valid = nxt_valid;
-                if (!valid) {
-                    if (nxt_valid) fetch(nxt.fx, nxt.fy);
-                    cur = nxt;
-                    continue;
-                }
-                dct_mb(nxt_valid, nxt.fx, nxt.fy);
-                cur = nxt;
+                int drawn = 0;
+                if (lane == 0) drawn = atomicAdd(&L.scalars[S_MB_NEXT], 1);
+                const bool valid = cur_o != kNoMb, nxt_valid = nxt_o != kNoMb;
+                const int nfx = (int)(nxt_o & 0xFFu), nfy = (int)(nxt_o >> 8);
+                const int mbe = (int)(cur_o & 0xFFu) * ny + (int)(cur_o >> 8);
+                if (valid) dct_mb(nxt_valid, nfx, nfy);
+                else if (nxt_valid) fetch(nfx, nfy);
+                cur_t = nxt_t;
+                cur_o = nxt_o;
+                nxt_t = __builtin_amdgcn_readfirstlane(drawn);
+                nxt_o = nxt_t < n_tickets ? order[nxt_t] : kNoMb;
+                if (!valid) continue;
                 mb_done++;
 
                 int ci[6];       // this lane's coefficient (scan position = lane) of each block; lane 0 (the DC slot) holds 0
@@ -1304,6 +1285,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_DONE] = np.done;
                     L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0;
                     L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
+                    L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                 } else {
                 if (count_scale) {
                     const int tb = L.scalars[S_CNT_F] + fixed_bits;
@@ -1323,6 +1305,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_RESULT] = st.best;
                 if (!np.done) {
                     L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0;
+                    L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                     if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
                 }
                 }
@@ -1350,7 +1333,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 for (int i = tid; i < max_size; i += kThreads) outp[i] = 0;
             if (tid == 0) {
                 psxhip_mdec_result_t r;
-                r.quant_scale = 64; r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
+                r.quant_scale = in_loop(64); r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
                 job.results[f] = r;
             }
             group_sync(5);      // everyone has read the verdict: the scalars may go
@@ -1614,6 +1597,24 @@ static int pick_it_step(int trips) {
     return 1;
 }
 
+// The order in which a pass's tickets visit the macroblocks: ticket t = (round r = t / waves, slot w = t % waves) visits
+// raster index w + ((r * step) % trips) * waves, with step coprime to trips and close to 0.382 trips -- any run of
+// tickets, in particular the first quarter the checkpoint looks at, is spread evenly over the frame.  Entries past the
+// last macroblock (the final round may be partial) hold kNoMb.  Returns the number of tickets (trips * waves).
+extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t* out, int cap) {
+    const int waves = large ? kWavesLarge : kWavesSmall;
+    const int nx = width / 16, ny = height / 16, nmb = nx * ny;
+    const int trips = (nmb + waves - 1) / waves, step = pick_it_step(trips);
+    const int n = trips * waves;
+    if (!out) return n;
+    for (int t = 0; t < n && t < cap; t++) {
+        const int r = t / waves, w = t % waves;
+        const int m = w + ((r * step) % trips) * waves;
+        out[t] = m < nmb ? (uint32_t)(m % nx) | (uint32_t)(m / nx) << 8 : kNoMb;
+    }
+    return n;
+}
+
 extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     const int waves_ = a->large ? kWavesLarge : kWavesSmall;
     FrameJob job;
@@ -1639,6 +1640,7 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.prio_pattern = a->prio_pattern;
     job.trips = (job.nmb + waves_ - 1) / waves_;
     job.it_step = pick_it_step(job.trips);
+    job.order = a->d_order;
     const int waves = waves_;
     const size_t lds = lds_bytes(job.nmb, job.out_words, job.stg_words, waves);
     const dim3 grid((unsigned)a->grid), block((unsigned)waves * 64u);

@@ -78,6 +78,7 @@ struct psxhip_mdec_ctx {
     unsigned int* d_ticket;         // [2] frame hand-out counters (the kernel re-arms them when it ends)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
+    uint32_t* d_order;              // the order a pass's tickets visit the macroblocks (psxhip_mdec_pass_order)
     // host-path staging: two chunk-sized sets of device buffers and pinned host buffers (double buffering)
     hipStream_t stream;
     uint8_t* d_frames[2];
@@ -195,6 +196,16 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(hipMalloc((void**)&c->d_ticket, 4 * sizeof(unsigned int)), PSXHIP_ENOMEM);
     HIP_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned int)), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    {
+        const int n = psxhip_mdec_pass_order(width, height, c->large, nullptr, 0);
+        uint32_t* h = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+        if (!h) { psxhip_set_error("out of host memory"); return PSXHIP_ENOMEM; }
+        (void)psxhip_mdec_pass_order(width, height, c->large, h, n);
+        hipError_t e = hipMalloc((void**)&c->d_order, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(c->d_order, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) { psxhip_set_error("pass order table: %s", hipGetErrorString(e)); return PSXHIP_ENOMEM; }
+    }
     if (const char* e = getenv("PSXHIP_MDEC_STATS")) {
         if (atoi(e)) {
             HIP_TRY(hipMalloc((void**)&c->d_stats, PSXHIP_MDEC_STATS_TOTAL * sizeof(unsigned long long)), PSXHIP_ENOMEM);
@@ -213,6 +224,7 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_stats) (void)hipFree(c->d_stats);
     psxhip_mdec_free_staging(c);
     for (int b = 0; b < 2; b++)
@@ -263,6 +275,7 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.large = c->large;
     a.stream = stream;
     a.d_ticket = c->d_ticket;
+    a.d_order = c->d_order;
     a.d_stats = c->d_stats;
     a.prio_pattern = c->prio_pattern;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);

@@ -33,12 +33,14 @@ typedef struct {
 	unsigned int *d_ticket;         /* [2] frame hand-out counters, zero between launches */
 	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
 	unsigned prio_pattern;          /* see FrameJob */
+	const uint32_t *d_order;        /* psxhip_mdec_pass_order() for this geometry, in device memory */
 } psxhip_mdec_launch_t;
 
 size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int stg_words, int large);
 int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
+int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int cap);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
 

@@ -102,3 +102,36 @@ def test_nothing_fits(sim):
     assert got == 64
     got, n = run(sim, tb, fb, 5000, 10000, 5)                                   # budget below the fixed cost
     assert got == 64 and n == 0
+
+
+@pytest.mark.parametrize("w,h,large", [(320, 240, 0), (320, 240, 1), (640, 480, 1), (160, 112, 0), (16, 16, 0), (1024, 1024, 1), (336, 240, 0)])
+def test_pass_order_visits_every_macroblock_once_and_spreads_the_first_quarter(w, h, large):
+    """The order in which a pass's tickets visit the macroblocks (psxhip_mdec_pass_order, host code of the library: no GPU
+    needed): a permutation of the frame's macroblocks plus padding, whose first quarter -- the sample the checkpoint
+    projects the frame's bits from -- touches every horizontal band of the frame about equally."""
+    from psxavenc_amd import _lib
+    L = _lib.lib()
+    L.psxhip_mdec_pass_order.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+    L.psxhip_mdec_pass_order.restype = C.c_int
+    n = L.psxhip_mdec_pass_order(w, h, large, None, 0)
+    waves = 16 if large else 12
+    nx, ny = w // 16, h // 16
+    nmb = nx * ny
+    assert n == -(-nmb // waves) * waves
+    buf = (C.c_uint32 * n)()
+    assert L.psxhip_mdec_pass_order(w, h, large, buf, n) == n
+    o = np.frombuffer(buf, dtype=np.uint32)
+    valid = o != 0xFFFF
+    assert valid.sum() == nmb
+    fx, fy = o[valid] & 0xFF, o[valid] >> 8
+    assert fx.max() < nx and fy.max() < ny
+    assert len(set((fy * nx + fx).tolist())) == nmb
+    if n // waves >= 8:
+        q = o[:(n // waves // 4) * waves]
+        q = q[q != 0xFFFF]
+        bands = np.bincount(((q >> 8) * 4 // ny).astype(np.int64), minlength=4)     # quarters of the frame's height
+        rounds = n // waves // 4
+        if rounds >= 8:
+            assert bands.min() * 3 >= bands.max(), bands
+        else:
+            assert (bands > 0).sum() >= min(rounds, 3), bands      # a handful of rounds cannot be even, only scattered
