@@ -962,8 +962,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             int emit_bits = 0, mb_done = 0;  // wave-uniform
             bool dense_prev = false;         // wave-uniform: the previous macroblock's list at the count scale was too long to walk
             // compaction threshold of this lane: smallest |n| that quantises to non-zero at the list's scale
+            // (|n| >= t  <=>  (unsigned)(n + t - 1) >= 2 t - 1: one add and one compare, no absolute value)
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
             const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
+            const uint32_t low_off = thr_low - 1u, low_span = 2u * thr_low - 1u, emit_off = thr_emit - 1u, emit_span = 2u * thr_emit - 1u;
             const uint32_t lane_tag = (uint32_t)lane << 17;
             // per-wavefront totals -> LDS (also used by the checkpoint: flushing resets the partial sums)
             auto flush = [&]() {
@@ -1044,20 +1046,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      everything expensive (VLC look-ups, bit positions, LDS writes) runs on a COMPACTED list, built once
                     //      per macroblock at the pass's LOWER scale (a coefficient that is non-zero at a coarser scale is non-zero
                     //      at every finer one): |n| quantises to non-zero  <=>  2|n| >= d  <=>  |n| >= ceil(d / 2).
-                    //      Entry: [15:0] |n|, [16] sign, [22:17] scan position.  Lane 0 (scan position 0) is always kept: it
+                    //      Entry: [16:0] n (17-bit two's complement), [22:17] scan position.  Lane 0 (scan position 0) is always kept: it
                     //      marks the block's DC slot, so the list is the macroblock's code sequence DC, AC..., DC, AC...
                     //      A macroblock that is dense at the count scale (a list of more than two chunks) is listed again at the
                     //      emit scale and counted in place (count_mb): walking a long list costs more than it saves.
-                    uint32_t mag[6];
-#pragma unroll
-                    for (int b = 0; b < 6; b++) mag[b] = (uint32_t)(ci[b] < 0 ? -ci[b] : ci[b]);
-                    auto build_list = [&](uint32_t thr) -> int {
+                    auto build_list = [&](uint32_t off, uint32_t span) -> int {
                         int c = 0;                             // wave-uniform
 #pragma unroll
                         for (int b = 0; b < 6; b++) {
-                            const uint64_t mk = wave::ballot(mag[b] >= thr) | 1ull;
-                            if (mag[b] >= thr || lane == 0)
-                                clist[c + wave::popc_below(mk)] = mag[b] | ((uint32_t)ci[b] & 0x10000u) | lane_tag;
+                            const bool keep = (uint32_t)ci[b] + off >= span;
+                            const uint64_t mk = wave::ballot(keep) | 1ull;
+                            if (keep || lane == 0) clist[c + wave::popc_below(mk)] = ((uint32_t)ci[b] & 0x1FFFFu) | lane_tag;
                             c += (int)__builtin_popcountll(mk);
                         }
                         return c;
@@ -1068,11 +1067,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (count_scale && dense_prev) {
                         int n_low = 0;
 #pragma unroll
-                        for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot(mag[b] >= thr_low));
+                        for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot((uint32_t)ci[b] + low_off >= low_span));
                         dense = n_low > 122;
                     }
                     if (!dense) {
-                        count = build_list(count_scale ? thr_low : thr_emit);
+                        count = count_scale ? build_list(low_off, low_span) : build_list(emit_off, emit_span);
                         list_low = count_scale != 0;
                         dense = count_scale && count > 128;
                     }
@@ -1084,7 +1083,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const int a = count_mb(cff, kc, lc, L.ac_len16);
                         acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
                         wave_sync();
-                        count = build_list(thr_emit);
+                        count = build_list(emit_off, emit_span);
                         list_low = false;
                     }
                     wave_sync();
@@ -1107,7 +1106,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const bool is_dc = k == 0;
                         const uint64_t dcm = wave::ballot(k == 0);        // (taken next to the compare: it folds into it)
                         const bool is_ac = live && !is_dc;
-                        const float magf = (float)(e & 0xFFFFu);
+                        const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
                         cnt16 = 0;
                         int kprev;
                         // the quantiser constants belong to the entry's scan position k, i.e. they sit in lane k's registers
@@ -1150,11 +1149,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         code = len == BS_ESCAPE_BITS ? esc : ((entry & 0x1FFFFu) | (neg ? 1u : 0u));
                         deficit = (int)((entry >> BS_LUT_DEFICIT_SHIFT) & 0xFu);
                         if (CODEC == 0) {
-                            // v2 DC slot: the entry carries the quantised DC as sign / magnitude; 10 bits (mdec.c:451-453), every
-                            // slot but the macroblock's first also carries the previous block's end-of-block code
+                            // v2 DC slot: the entry carries the quantised DC; 10 bits (mdec.c:451-453), every slot but the
+                            // macroblock's first also carries the previous block's end-of-block code
                             if (is_dc) {
-                                const uint32_t m = e & 0xFFFFu;
-                                const uint32_t dcv10 = (neg ? 0u - m : m) & 0x3FFu;
+                                const uint32_t dcv10 = e & 0x3FFu;
                                 code = i != 0 ? dcv10 | (2u << 10) : dcv10;
                                 len = i != 0 ? 12 : 10;
                             }
@@ -1203,7 +1201,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             const int k = (int)((e >> 17) & 63u);
                             const bool is_dc = k == 0;
                             const bool is_ac = live && !is_dc;
-                            const float magf = (float)(e & 0xFFFFu);
+                            const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
                             QuantK ck, ek;
                             ck.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, kc.inv)));
                             ck.bias = __builtin_fmaf(0.25f, ck.inv, 0.5f);
