@@ -72,7 +72,10 @@ int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t *ctx, const uint8_t *d_fr
                                      void *stream);
 
 /* Same, host buffers: H2D, kernel, D2H, synchronise.  frame_max_sizes may be NULL (uniform).
- * Returns PSXHIP_ENOFIT if any frame could not be fitted (its result has quant_scale 64). */
+ * Returns PSXHIP_ENOFIT if any frame could not be fitted (its result has quant_scale 64).
+ * The batch moves in chunks over two streams (the copies of one chunk overlap the kernel of the next).  Pageable `frames`
+ * / `out` go through pinned staging buffers (a multi-threaded CPU copy per chunk); buffers that are page-locked --
+ * hipHostMalloc, hipHostRegister or psxhip_host_register() below -- are read and written by DMA directly. */
 int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t *ctx, const uint8_t *frames, int n_frames,
                                    const int32_t *frame_max_sizes, int uniform_max_size, uint8_t *out,
                                    size_t out_stride, psxhip_mdec_result_t *results);
@@ -212,6 +215,12 @@ int psxhip_xa_encode_streams_host(int device, int format, int stereo, int freque
 /* The host-buffer ADPCM entry points keep their device scratch buffers per calling thread between calls (the reference
  * calls them once per 28 samples / once per sector); this releases the calling thread's. */
 void psxhip_release_scratch(void);
+
+/* Page-lock a caller-owned host buffer (hipHostRegister) so that the *_host entry points move it by DMA without a
+ * staging copy; worth it for buffers that live across many calls (registration costs about as much as copying the
+ * buffer once).  Unregister before freeing the memory. */
+int psxhip_host_register(void *p, size_t bytes);
+int psxhip_host_unregister(void *p);
 
 /* ---------------------------------------------------------------- STR / STRCD / STRV muxer -- */
 

@@ -88,6 +88,8 @@ struct psxhip_mdec_ctx {
     uint8_t* h_in[2];                 // pinned
     uint8_t* h_out[2];                // pinned: output rows, then the chunk's results
     hipEvent_t chunk_done[2];
+    hipStream_t stream2;             // chunks alternate between the two streams: the copies of one overlap the kernel of the other
+    hipEvent_t kernel_done[2];       // ... while the kernels stay ordered (launches on a context are stream-ordered)
     int cap_frames;                   // frames per chunk the buffers hold
     size_t cap_out_stride;
 };
@@ -196,6 +198,8 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(hipMalloc((void**)&c->d_ticket, 4 * sizeof(unsigned int)), PSXHIP_ENOMEM);
     HIP_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned int)), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->kernel_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
     {
         const int n = psxhip_mdec_pass_order(width, height, c->large, nullptr, 0);
         uint32_t* h = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
@@ -223,13 +227,17 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_stats) (void)hipFree(c->d_stats);
     psxhip_mdec_free_staging(c);
     for (int b = 0; b < 2; b++)
         if (c->chunk_done[b]) (void)hipEventDestroy(c->chunk_done[b]);
+    for (int b = 0; b < 2; b++)
+        if (c->kernel_done[b]) (void)hipEventDestroy(c->kernel_done[b]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     free(c);
 }
 
@@ -299,6 +307,18 @@ static void psxhip_mdec_free_staging(psxhip_mdec_ctx* c) {
 
 namespace {
 // copy `bytes` with a few threads: one core moves ~10 GB/s, a pinned staging buffer can take several times that
+// is this host pointer page-locked memory the runtime knows about (hipHostMalloc / hipHostRegister)?
+bool host_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // pageable memory is reported as an error by some runtimes: not one of ours
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 void parallel_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
     static const unsigned hw = std::thread::hardware_concurrency();
     unsigned t = bytes >= (8u << 20) ? (hw >= 16 ? 8u : (hw >= 4 ? hw / 2 : 1u)) : 1u;
@@ -372,11 +392,17 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
     }
     const size_t os = c->cap_out_stride;
     const int n_chunks = (n_frames + chunk - 1) / chunk;
+    // Callers whose buffers are page-locked (hipHostMalloc, hipHostRegister / psxhip_host_register) are served by DMA
+    // straight from / to their memory; pageable buffers go through the pinned staging buffers, copied by the CPU while the
+    // GPU works on the neighbouring chunks.
+    const bool in_pinned = host_pinned(frames), out_pinned = host_pinned(out);
     // hand a finished chunk to the caller
     auto deliver = [&](int k) {
         const int b = k & 1, first = k * chunk, cnt = (first + chunk <= n_frames) ? chunk : n_frames - first;
         const uint8_t* src = c->h_out[b];
-        if (os == out_stride) {
+        if (out_pinned) {
+            // (already there)
+        } else if (os == out_stride) {
             parallel_copy(out + (size_t)first * out_stride, src, os * (size_t)cnt);
         } else {
             for (int i = 0; i < cnt; i++) memcpy(out + (size_t)(first + i) * out_stride, src + (size_t)i * os, (size_t)max_size);
@@ -385,26 +411,40 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
     };
     for (int k = 0; k < n_chunks; k++) {
         const int b = k & 1, first = k * chunk, cnt = (first + chunk <= n_frames) ? chunk : n_frames - first;
+        hipStream_t st = b ? c->stream2 : c->stream;
         if (k >= 2) {
             HIP_TRY(hipEventSynchronize(c->chunk_done[b]), PSXHIP_EDEVICE);      // chunk k-2 left the GPU: its buffers are free
             deliver(k - 2);
         }
-        parallel_copy(c->h_in[b], frames + (size_t)first * fsz, fsz * (size_t)cnt);
-        HIP_TRY(hipMemcpyAsync(c->d_frames[b], c->h_in[b], fsz * (size_t)cnt, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
+        const uint8_t* src = frames + (size_t)first * fsz;
+        if (!in_pinned) {
+            parallel_copy(c->h_in[b], src, fsz * (size_t)cnt);
+            src = c->h_in[b];
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_frames[b], src, fsz * (size_t)cnt, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
         if (frame_max_sizes) {
             int32_t* hs = (int32_t*)(c->h_in[b] + fsz * (size_t)c->cap_frames);
             memcpy(hs, frame_max_sizes + first, sizeof(int32_t) * (size_t)cnt);
-            HIP_TRY(hipMemcpyAsync(c->d_sizes[b], hs, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, c->stream), PSXHIP_EDEVICE);
+            HIP_TRY(hipMemcpyAsync(c->d_sizes[b], hs, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
             // rows are handed back max_size wide; bytes past a frame's own (smaller) budget read as zero
-            HIP_TRY(hipMemsetAsync(c->d_out[b], 0, os * (size_t)cnt, c->stream), PSXHIP_EDEVICE);
+            HIP_TRY(hipMemsetAsync(c->d_out[b], 0, os * (size_t)cnt, st), PSXHIP_EDEVICE);
         }
+        // the kernels of consecutive chunks run in order (they share the context's frame tickets); everything else of a
+        // chunk overlaps its neighbours
+        if (k >= 1) HIP_TRY(hipStreamWaitEvent(st, c->kernel_done[b ^ 1], 0), PSXHIP_EDEVICE);
         int rc = psxhip_mdec_encode_frames_device(c, c->d_frames[b], fsz, cnt, frame_max_sizes ? c->d_sizes[b] : nullptr,
-                                                  uniform_max_size, c->d_out[b], os, c->d_res[b], c->stream);
+                                                  uniform_max_size, c->d_out[b], os, c->d_res[b], st);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_out[b], c->d_out[b], os * (size_t)cnt, hipMemcpyDeviceToHost, c->stream), PSXHIP_EDEVICE);
+        HIP_TRY(hipEventRecord(c->kernel_done[b], st), PSXHIP_EDEVICE);
+        if (out_pinned) {
+            HIP_TRY(hipMemcpy2DAsync(out + (size_t)first * out_stride, out_stride, c->d_out[b], os, (size_t)max_size, (size_t)cnt,
+                                     hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_out[b], c->d_out[b], os * (size_t)cnt, hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+        }
         HIP_TRY(hipMemcpyAsync(c->h_out[b] + os * (size_t)c->cap_frames, c->d_res[b], sizeof(psxhip_mdec_result_t) * (size_t)cnt,
-                               hipMemcpyDeviceToHost, c->stream), PSXHIP_EDEVICE);
-        HIP_TRY(hipEventRecord(c->chunk_done[b], c->stream), PSXHIP_EDEVICE);
+                               hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);
+        HIP_TRY(hipEventRecord(c->chunk_done[b], st), PSXHIP_EDEVICE);
     }
     for (int k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; k++) {
         HIP_TRY(hipEventSynchronize(c->chunk_done[k & 1]), PSXHIP_EDEVICE);
@@ -416,6 +456,18 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
                              frame_max_sizes ? frame_max_sizes[i] : uniform_max_size);
             return PSXHIP_ENOFIT;
         }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return PSXHIP_EINVAL;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault), PSXHIP_EDEVICE);
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_host_unregister(void* p) {
+    if (!p) return PSXHIP_EINVAL;
+    HIP_TRY(hipHostUnregister(p), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }
 

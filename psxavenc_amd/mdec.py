@@ -65,7 +65,9 @@ class MdecEncoder:
         return self.frame_output
 
     # ---- batched host path ------------------------------------------------------------------------
-    def encode_frames_host(self, frames, frame_max_sizes):
+    def encode_frames_host(self, frames, frame_max_sizes, out=None, res=None):
+        """frames: (n, w*h*3/2) uint8 host array.  `out` / `res`: optional preallocated (n, stride) uint8 / (n, 4) int32
+        arrays (e.g. page-locked ones, see register_host()) -- the library then writes into them instead of fresh memory."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n = frames.shape[0]
         assert frames.shape[1] == self.frame_bytes
@@ -74,8 +76,12 @@ class MdecEncoder:
         else:
             sizes = np.ascontiguousarray(frame_max_sizes, dtype=np.int32)
             sizes_p, uniform, stride = sizes.ctypes.data, 0, int(sizes.max())
-        out = np.zeros((n, stride), dtype=np.uint8)
-        res = np.zeros((n, 4), dtype=np.int32)
+        if out is None:
+            out = np.zeros((n, stride), dtype=np.uint8)
+        if res is None:
+            res = np.zeros((n, 4), dtype=np.int32)
+        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (n, stride)
+        assert res.dtype == np.int32 and res.flags.c_contiguous and res.shape == (n, 4)
         rc = _lib.lib().psxhip_mdec_encode_frames_host(self._h, frames.ctypes.data, n, sizes_p, uniform,
                                                        out.ctypes.data, stride, res.ctypes.data)
         _lib.check(rc)
@@ -103,3 +109,16 @@ class MdecEncoder:
                                                          d_results.data_ptr(), st.cuda_stream)
         _lib.check(rc)
         return d_out, d_results
+
+
+def register_host(a):
+    """Page-lock a numpy array's memory (psxhip_host_register): the host entry points then move it by DMA, no staging copy."""
+    L = _lib.lib()
+    L.psxhip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    _lib.check(L.psxhip_host_register(a.ctypes.data, a.nbytes))
+
+
+def unregister_host(a):
+    L = _lib.lib()
+    L.psxhip_host_unregister.argtypes = [C.c_void_p]
+    _lib.check(L.psxhip_host_unregister(a.ctypes.data))

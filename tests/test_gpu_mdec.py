@@ -399,3 +399,37 @@ def test_large_budgets_assemble_the_frame_image_in_tiles():
                 assert np.array_equal(out[k, :budgets[k]], want[k, :budgets[k]]), (codec, w, h, amp, k, int(budgets[k]))
                 assert np.array_equal(res[k], want_res[k])
         enc.close()
+
+
+def test_host_path_chunks_over_two_streams_and_page_locked_buffers():
+    """encode_frames_host moves a batch in chunks that alternate between two streams (kernels stay ordered), and serves
+    page-locked caller buffers by DMA without the staging copy -- a strided 2-D copy when the caller's rows are wider than
+    the budget.  2600 frames = three chunks; pageable and page-locked runs must both equal the oracle."""
+    from psxavenc_amd import _lib
+    from psxavenc_amd.mdec import MdecEncoder, register_host, unregister_host
+    import ctypes as C
+    w, h, n = 160, 112, 2600
+    fr = O.synth_frames(w, h, n, seed=21, amp=6)
+    budgets = (1400 + 8 * (np.arange(n) % 60)).astype(np.int32)
+    want, want_res, rc = O.mdec_encode(1, w, h, fr, budgets, stride=int(budgets.max()))
+    assert rc == 0
+    enc = MdecEncoder(1, w, h, max_frame_size=int(budgets.max()))
+    out, res = enc.encode_frames_host(fr, budgets)
+    assert np.array_equal(out, want) and np.array_equal(res, want_res)
+    # page-locked input and a page-locked output with rows wider than the largest budget
+    stride = int(budgets.max()) + 52
+    wide = np.full((n, stride), 0xEE, dtype=np.uint8)
+    res2 = np.zeros((n, 4), dtype=np.int32)
+    frp = fr.copy()
+    register_host(frp)
+    register_host(wide)
+    try:
+        rc = _lib.lib().psxhip_mdec_encode_frames_host(enc._h, frp.ctypes.data, n, budgets.ctypes.data, 0, wide.ctypes.data,
+                                                       stride, res2.ctypes.data)
+        _lib.check(rc)
+    finally:
+        unregister_host(frp)
+        unregister_host(wide)
+    assert np.array_equal(wide[:, :int(budgets.max())], want) and np.array_equal(res2, want_res)
+    assert (wide[:, int(budgets.max()):] == 0xEE).all()          # bytes past the row's budget width are the caller's
+    enc.close()

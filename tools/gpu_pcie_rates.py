@@ -25,3 +25,22 @@ t = time.perf_counter()
 for _ in range(3): enc.encode_frames_host(fr8, budget)
 dt = (time.perf_counter() - t) / 3
 print("encode_frames_host (8000 frames per call, pageable host buffers, chunked double-buffered pipeline): %.0f frames/s (%.2f ms per call)" % (8000 / dt, dt * 1e3))
+
+# page-locked caller buffers: no staging copy, DMA straight from / to the caller's memory
+from psxavenc_amd.mdec import register_host, unregister_host
+out8 = np.zeros((8000, budget), dtype=np.uint8); res8 = np.zeros((8000, 4), dtype=np.int32)
+t = time.perf_counter(); enc.encode_frames_host(fr8, budget, out=out8, res=res8); dt0 = time.perf_counter() - t
+for _ in range(2): enc.encode_frames_host(fr8, budget, out=out8, res=res8)
+t = time.perf_counter()
+for _ in range(3): enc.encode_frames_host(fr8, budget, out=out8, res=res8)
+dt = (time.perf_counter() - t) / 3
+print("encode_frames_host (8000 frames per call, pageable, preallocated output): %.0f frames/s (%.2f ms per call)" % (8000 / dt, dt * 1e3))
+want = out8.copy()
+t = time.perf_counter(); register_host(fr8); register_host(out8); dtr = time.perf_counter() - t
+enc.encode_frames_host(fr8, budget, out=out8, res=res8)
+t = time.perf_counter()
+for _ in range(3): enc.encode_frames_host(fr8, budget, out=out8, res=res8)
+dt = (time.perf_counter() - t) / 3
+print("encode_frames_host (8000 frames per call, PAGE-LOCKED caller buffers, DMA direct): %.0f frames/s (%.2f ms per call); registering 987 MB took %.0f ms; output identical: %s"
+      % (8000 / dt, dt * 1e3, dtr * 1e3, np.array_equal(out8, want)))
+unregister_host(fr8); unregister_host(out8)
