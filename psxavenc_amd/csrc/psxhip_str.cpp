@@ -25,6 +25,11 @@ namespace {
 std::mutex g_ctx_mu;
 psxhip_mdec_ctx_t* g_ctx = nullptr;
 int g_ctx_key[5] = {-1, -1, -1, -1, -1};      // device, codec, width, height, max_frame_size
+// ... and so is the buffer the frames' bitstreams land in before they are cut into sectors: page-locked, so the MDEC host
+// path writes it by DMA; calls are serialised on it
+std::mutex g_call_mu;
+uint8_t* g_bs = nullptr;
+size_t g_bs_cap = 0;
 
 void put_le16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 void put_le32(uint8_t* p, unsigned v) { put_le16(p, v & 0xFFFF); put_le16(p + 2, v >> 16); }
@@ -123,10 +128,14 @@ int make_plan(const psxhip_str_settings_t* s, int n_frames, Plan* pl) {
 }  // namespace
 
 extern "C" void psxhip_str_release(void) {
+    std::lock_guard<std::mutex> call(g_call_mu);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     psxhip_mdec_destroy(g_ctx);
     g_ctx = nullptr;
     g_ctx_key[0] = -1;
+    if (g_bs) (void)hipHostFree(g_bs);
+    g_bs = nullptr;
+    g_bs_cap = 0;
 }
 
 extern "C" int psxhip_str_plan(const psxhip_str_settings_t* settings, int n_frames, psxhip_str_plan_t* plan) {
@@ -163,9 +172,22 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
         return PSXHIP_EINVAL;
     }
 
-    // ---- video: every frame in one batched call (its own stream inside the context)
+    // ---- video: every frame in one batched call (its own streams inside the context)
+    std::lock_guard<std::mutex> call(g_call_mu);
     const size_t ostride = (size_t)pl.pub.max_frame_size;
-    std::vector<uint8_t> bs((size_t)n_frames * ostride);
+    if ((size_t)n_frames * ostride > g_bs_cap) {
+        if (hipSetDevice(device) != hipSuccess) { psxhip_set_error("psxhip_str_encode_host: no such device %d", device); return PSXHIP_EDEVICE; }
+        if (g_bs) (void)hipHostFree(g_bs);
+        g_bs = nullptr;
+        g_bs_cap = 0;
+        if (hipHostMalloc((void**)&g_bs, (size_t)n_frames * ostride, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            psxhip_set_error("psxhip_str_encode_host: out of pinned host memory (%zu bytes)", (size_t)n_frames * ostride);
+            return PSXHIP_ENOMEM;
+        }
+        g_bs_cap = (size_t)n_frames * ostride;
+    }
+    uint8_t* const bs = g_bs;
     std::vector<psxhip_mdec_result_t> res((size_t)n_frames);
     int rc_video = PSXHIP_OK;
     char err_video[256] = "";
@@ -179,7 +201,7 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
             if (rc_video == PSXHIP_OK) memcpy(g_ctx_key, key, sizeof key);
         }
         if (rc_video == PSXHIP_OK)
-            rc_video = psxhip_mdec_encode_frames_host(g_ctx, frames, n_frames, pl.budgets.data(), 0, bs.data(), ostride, res.data());
+            rc_video = psxhip_mdec_encode_frames_host(g_ctx, frames, n_frames, pl.budgets.data(), 0, bs, ostride, res.data());
         if (rc_video) snprintf(err_video, sizeof err_video, "%s", psxhip_last_error());     // thread-local text
     });
 
@@ -264,7 +286,7 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
                     sub[1] = sub[0];
                 }
                 // the 32-byte chunk header + 2016 payload bytes of encode_sector_str, mdec.c:782-832
-                const uint8_t* fo = bs.data() + (size_t)frame * ostride;
+                const uint8_t* fo = bs + (size_t)frame * ostride;
                 uint8_t* hd = sector + at;
                 put_le16(hd + 0x00, 0x0160);
                 put_le16(hd + 0x02, (unsigned)s->str_video_id);

@@ -53,12 +53,16 @@ def frame_budgets(s, first_frame, n_frames):
     return out
 
 
-def encode(s, frames, pcm=None, device=0):
-    """frames: (n, w*h*3/2) uint8; pcm: int16, interleaved when stereo.  Returns (sectors (n_sectors, sector_size) uint8, plan)."""
+def encode(s, frames, pcm=None, device=0, out=None):
+    """frames: (n, w*h*3/2) uint8; pcm: int16, interleaved when stereo.  Returns (sectors (n_sectors, sector_size) uint8, plan).
+    `out`: optional preallocated (n_sectors, sector_size) uint8 array to write into (a caller muxing stream after stream
+    reuses its buffer instead of faulting in 23 MB of fresh pages per call)."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     n = frames.shape[0]
     p = plan(s, n)
-    out = np.zeros((p.n_sectors, p.sector_size), np.uint8)
+    if out is None:
+        out = np.zeros((p.n_sectors, p.sector_size), np.uint8)
+    assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (p.n_sectors, p.sector_size)
     if pcm is None:
         pcm = np.zeros(0, np.int16)
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
