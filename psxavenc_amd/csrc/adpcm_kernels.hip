@@ -25,7 +25,11 @@ namespace {
 
 constexpr int kRecordBytes = 32;   // [0] header, [4..31] 28 codes
 
-__device__ __forceinline__ int predict(int k1, int k2, int p1, int p2) { return (k1 * p1 + k2 * p2 + 32) >> 6; }
+// (k1 p1 + k2 p2 + 32) >> 6  (adpcm.c:63,106).  Taps and history fit 24 bits (|k| <= 122, history is int16): full-rate
+// 24-bit multiply-adds, and the p2 product is off the recursion's critical path.
+__device__ __forceinline__ int predict(int k1, int k2, int p1, int p2) {
+    return (__mul24(k1, p1) + (__mul24(k2, p2) + 32)) >> 6;
+}
 
 template <int CTRL>
 __device__ __forceinline__ uint64_t dpp64(uint64_t v) {
@@ -102,9 +106,13 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
             p1 = xi;
         }
     }
-    int rs = 0;
-    while (rs < cd.range && (hi >> rs) > cd.qmax) rs++;
-    while (rs < cd.range && (lo >> rs) < cd.qmin) rs++;
+    // the two while loops of adpcm.c:72-73 in closed form: hi >> rs <= qmax = 2^(15 - range) - 1 and lo >> rs >= qmin =
+    // -2^(15 - range) both say "bit length of max(hi, ~lo) minus rs is at most 15 - range" (hi >= 0 >= lo), so
+    // rs = clamp(bit_length(max(hi, ~lo)) - (15 - range), 0, range); tests/test_adpcm_oracle.py checks it against the loops.
+    // (As loops they compiled to ~200 instructions of lane-divergent control flow per unit.)
+    const int widest = hi > ~lo ? hi : ~lo;
+    int rs = (widest > 0 ? 32 - __clz(widest) : 0) - (15 - cd.range);
+    rs = rs < 0 ? 0 : (rs > cd.range ? cd.range : rs);
     const int m = cd.range - rs;
     const int shift = m - 1 + cd.which;
     const bool valid = unit_live && cd.live && shift >= 0 && shift <= cd.range;
@@ -124,14 +132,15 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
             q = (q + cd.half) >> cd.range;
             q = q < cd.qmin ? cd.qmin : q;
             q = q > cd.qmax ? cd.qmax : q;
-            q &= cd.qmask;
-            int dec = (int)(int16_t)(uint16_t)(q << cd.range);
-            dec = (dec >> sh) + pred;
+            // adpcm.c:118-123 masks the code to (16 - range) bits, shifts it to the top of an int16, sign-extends and shifts
+            // right by `shift`.  For a clamped code that is q << range, exactly representable, and shift <= range: the decoded
+            // step is q << (range - shift) -- one shift-add on the recursion's critical path instead of five operations.
+            int dec = (q << (cd.range - sh)) + pred;
             dec = dec > 0x7FFF ? 0x7FFF : dec;
             dec = dec < -0x8000 ? -0x8000 : dec;
             const int err = dec - xi;
             sse += (uint64_t)((int64_t)err * (int64_t)err);
-            pk |= (uint32_t)q << (8 * j);
+            pk |= (uint32_t)(q & cd.qmask) << (8 * j);
             p2 = p1;
             p1 = dec;
         }
@@ -335,24 +344,37 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     int n_max = n_run;
     n_max = max(n_max, __shfl_xor(n_max, 16, 64));
     n_max = max(n_max, __shfl_xor(n_max, 32, 64));
+    // Software pipeline: while unit t is encoded, the samples of unit t + 1 and (verify) the state stored for it are on
+    // their way; they are staged into the other LDS buffer right after the encode -- by then they have arrived and nothing
+    // younger is in flight -- and only then this unit's record and state are stored.  The loop never waits for a store.
+    // (Loading the stored state where it is compared cost two exposed global round trips per unit: 2.3 us instead of 1.)
     bool running = active;
+    __shared__ int xs_alt[4][32];
+    int* xs_a = xs;
+    int* xs_b = xs_alt[lane >> 4];
     UnitFetch nxt = fetch_unit(src, ch, first, running && 0 < n_run, lane);
+    psxhip_adpcm_state_t old_nxt;
+    old_nxt.prev1 = 0;
+    old_nxt.prev2 = 0;
+    if (VERIFY && running && 0 < n_run) old_nxt = job.unit_states[st0 + first];
+    stage_unit(xs_a, nxt, lane);
     for (int t = 0; t < n_max; t++) {
         const bool live = running && t < n_run;
         if (!__any(live)) break;
         const int u = first + t;
-        stage_unit(xs, nxt, lane);
-        if (t + 1 < n_max) nxt = fetch_unit(src, ch, u + 1, running && t + 1 < n_run, lane);   // prefetch
-        uint32_t header;
-        const bool winner = encode_unit(cd, xs, live, lane, prev1, prev2, header, pk_lds);
-        if (VERIFY && live) {
-            // coincided with the state stored for this unit: everything after it is already consistent
-            const psxhip_adpcm_state_t old = job.unit_states[st0 + u];
-            if (old.prev1 == prev1 && old.prev2 == prev2) {
-                // the record of THIS unit may still differ (different start, same end), so write it, then stop
-                running = false;
-            }
+        const psxhip_adpcm_state_t old = old_nxt;
+        const bool more = t + 1 < n_max;
+        if (more) {
+            const bool nlive = running && t + 1 < n_run;
+            nxt = fetch_unit(src, ch, u + 1, nlive, lane);
+            if (VERIFY && nlive) old_nxt = job.unit_states[st0 + u + 1];
         }
+        uint32_t header;
+        const bool winner = encode_unit(cd, xs_a, live, lane, prev1, prev2, header, pk_lds);
+        // (verify) coincided with the state stored for this unit: everything after it is already consistent.  The record of
+        // THIS unit may still differ (different start, same end), so it is written, then the chunk stops.
+        if (VERIFY && live && old.prev1 == prev1 && old.prev2 == prev2) running = false;
+        if (more) stage_unit(xs_b, nxt, lane);
         if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
         if (live && (lane & 15) == 0) {
             psxhip_adpcm_state_t s1;
@@ -360,6 +382,9 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
             s1.prev2 = prev2;
             job.unit_states[st0 + u] = s1;
         }
+        int* const swap = xs_a;
+        xs_a = xs_b;
+        xs_b = swap;
     }
 }
 
@@ -557,13 +582,59 @@ __global__ void adpcm_gather_final_states_kernel(const psxhip_adpcm_chain_t* cha
 }
 
 namespace {
+// A session owns a dozen device buffers.  The one-call entry points (psxhip_adpcm_encode_chains_chunked and the *_host
+// wrappers above it) build and drop a session per call, and a dozen hipMalloc / hipFree pairs cost more than encoding a
+// minute of audio: freed blocks are parked per host thread and handed out again (smallest block that fits and is not more
+// than four times too large).  psxhip_release_scratch() empties the cache.  A session synchronises its stream before it
+// lets go of its buffers, so a parked block has no work in flight.
+struct BlockCache {
+    static constexpr int kMax = 32;
+    struct Entry { void* p; size_t cap; int device; };
+    Entry e[kMax];
+    int n = 0;
+    void* take(size_t need, int device, size_t* cap) {
+        int best = -1;
+        for (int i = 0; i < n; i++)
+            if (e[i].device == device && e[i].cap >= need && e[i].cap <= 4 * need + 4096 && (best < 0 || e[i].cap < e[best].cap)) best = i;
+        if (best < 0) return nullptr;
+        void* p = e[best].p;
+        *cap = e[best].cap;
+        e[best] = e[--n];
+        return p;
+    }
+    bool park(void* p, size_t cap, int device) {
+        if (n == kMax) return false;
+        e[n++] = Entry{p, cap, device};
+        return true;
+    }
+    void release() {
+        for (int i = 0; i < n; i++) (void)hipFree(e[i].p);
+        n = 0;
+    }
+    ~BlockCache() { release(); }
+};
+thread_local BlockCache g_blocks;
+
 struct DevMem {
     void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    size_t cap = 0;
+    int device = 0;
+    ~DevMem() {
+        if (p && !g_blocks.park(p, cap, device)) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) {
+        if (!n) n = 4;
+        (void)hipGetDevice(&device);
+        p = g_blocks.take(n, device, &cap);
+        if (p) return hipSuccess;
+        cap = (n + 255) & ~(size_t)255;
+        return hipMalloc(&p, cap);
+    }
     template <typename T> T* as() { return (T*)p; }
 };
 }  // namespace
+
+extern "C" void psxhip_adpcm_release_blocks(void) { g_blocks.release(); }
 
 struct psxhip_adpcm_session {
     int device, n_chains, n_chunks;

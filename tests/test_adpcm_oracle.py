@@ -149,3 +149,28 @@ def test_edc_crc_properties():
     for _ in range(8):
         v = (v >> 1) ^ (0xD8018001 if v & 1 else 0)
     assert L.orc_edc_crc32(O.ptr(one, O.u8p), 1) == v
+
+
+def test_min_shift_closed_form_equals_the_reference_loops():
+    """adpcm.c:72-73 finds the right shift with two while loops; the HIP kernel (adpcm_kernels.hip, encode_unit) uses
+    clamp(bit_length(max(s_max, ~s_min)) - (15 - range), 0, range).  Same function for every reachable operand."""
+    def loops(hi, lo, rng):
+        rs = 0
+        while rs < rng and (hi >> rs) > (0x7FFF >> rng):
+            rs += 1
+        while rs < rng and (lo >> rs) < (-0x8000 >> rng):
+            rs += 1
+        return rs
+
+    def closed(hi, lo, rng):
+        m = max(hi, ~lo)
+        return min(max((m.bit_length() if m > 0 else 0) - (15 - rng), 0), rng)
+
+    rnd = np.random.default_rng(3)
+    edges = sorted({0, 1} | {(1 << k) + d for k in range(1, 19) for d in (-1, 0, 1)})
+    for rng in (8, 12):
+        for hi in edges:
+            for lo in edges:
+                assert loops(hi, -lo, rng) == closed(hi, -lo, rng), (hi, -lo, rng)
+        for hi, lo in zip(rnd.integers(0, 1 << 18, 20000).tolist(), rnd.integers(0, 1 << 18, 20000).tolist()):
+            assert loops(hi, -lo, rng) == closed(hi, -lo, rng), (hi, -lo, rng)
