@@ -119,36 +119,45 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
     const int sh = valid ? shift : 0;
 
     // ---- attempt_to_encode for (filter, shift) (adpcm.c:81-140)
-    uint64_t sse = 0;
+    // The squared error is summed in 32 bits with saturation: the candidate (filter 0, shift m) never clips -- its error is
+    // at most one quantiser step, 2^12, per sample, 28 * 2^24 < 2^29 in total -- so the minimum is always below 2^32 and a
+    // candidate that saturates cannot be it.  (A 64-bit multiply-add per sample costs four issue slots.)
+    uint32_t sse = 0;
     int p1 = prev1, p2 = prev2;
+    const int qmin_v = cd.qmin;
+    const uint32_t up = (uint32_t)(cd.range - sh);
+    const uint32_t mask4 = (uint32_t)cd.qmask * 0x01010101u;
 #pragma unroll 1
     for (int w = 0; w < 7; w++) {
-        uint32_t pk = 0;
+        int qs[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int xi = xs[w * 4 + j];
             const int pred = predict(cd.k1, cd.k2, p1, p2);
             int q = (int)((uint32_t)(xi - pred) << sh);
             q = (q + cd.half) >> cd.range;
-            q = q < cd.qmin ? cd.qmin : q;
-            q = q > cd.qmax ? cd.qmax : q;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(q) : "v"(q), "v"(qmin_v), "s"(cd.qmax));      // clamp to [qmin, qmax]
             // adpcm.c:118-123 masks the code to (16 - range) bits, shifts it to the top of an int16, sign-extends and shifts
             // right by `shift`.  For a clamped code that is q << range, exactly representable, and shift <= range: the decoded
             // step is q << (range - shift) -- one shift-add on the recursion's critical path instead of five operations.
-            int dec = (q << (cd.range - sh)) + pred;
+            int dec;
+            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(dec) : "v"(q), "v"(up), "v"(pred));
             dec = dec > 0x7FFF ? 0x7FFF : dec;
             dec = dec < -0x8000 ? -0x8000 : dec;
-            const int err = dec - xi;
-            sse += (uint64_t)((int64_t)err * (int64_t)err);
-            pk |= (uint32_t)(q & cd.qmask) << (8 * j);
+            const int err = dec - xi;                              // |err| <= 65535: the low 32 bits of the 24-bit product are its square
+            sse = __builtin_elementwise_add_sat(sse, (uint32_t)__mul24(err, err));
+            qs[j] = q;
             p2 = p1;
             p1 = dec;
         }
-        pk_lds[w * 64 + lane] = pk;
+        // the codes are the low (16 - range) <= 8 bits of the clamped values: gather the four low bytes, mask once
+        const uint32_t lo = __builtin_amdgcn_perm((uint32_t)qs[1], (uint32_t)qs[0], 0x0C0C0400u);
+        const uint32_t hi = __builtin_amdgcn_perm((uint32_t)qs[3], (uint32_t)qs[2], 0x04000C0Cu);
+        pk_lds[w * 64 + lane] = (lo | hi) & mask4;
     }
 
     // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
-    const uint64_t key = valid ? ((sse << 8) | ((uint64_t)cd.f << 4) | (uint64_t)sh) : ~0ull;
+    const uint64_t key = valid ? (((uint64_t)sse << 8) | ((uint64_t)cd.f << 4) | (uint64_t)sh) : ~0ull;
     const uint64_t best = row_min_u64(key);
     const bool winner = valid && key == best;
     const uint64_t wmask = __ballot(winner);

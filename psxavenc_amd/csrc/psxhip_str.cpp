@@ -315,7 +315,7 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
     };
     {
         const unsigned hw = std::thread::hardware_concurrency();
-        int nt = ns >= 2048 ? (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1)) : 1;
+        int nt = ns >= 2048 ? (hw >= 64 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1))) : 1;
         std::vector<std::thread> th;
         const int per = (ns + nt - 1) / nt;
         for (int t = 1; t < nt; t++)
