@@ -28,7 +28,10 @@ constexpr int kRecordBytes = 32;   // [0] header, [4..31] 28 codes
 // (k1 p1 + k2 p2 + 32) >> 6  (adpcm.c:63,106).  Taps and history fit 24 bits (|k| <= 122, history is int16): full-rate
 // 24-bit multiply-adds, and the p2 product is off the recursion's critical path.
 __device__ __forceinline__ int predict(int k1, int k2, int p1, int p2) {
-    return (__mul24(k1, p1) + (__mul24(k2, p2) + 32)) >> 6;
+    int t, r;
+    asm("v_mad_i32_i24 %0, %1, %2, 32" : "=v"(t) : "v"(k2), "v"(p2));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(k1), "v"(p1), "v"(t));
+    return r >> 6;
 }
 
 template <int CTRL>
@@ -62,6 +65,7 @@ struct ChainJob {
 // Per-lane constants of the candidate this lane owns inside its 16-lane row.
 struct Candidate {
     int f, which, k1, k2;
+    int peer_a, peer_b;      // byte addresses (lane * 4) of the two other lanes that try this lane's filter
     bool live;
     int range, qmin, qmax, qmask, half;
 };
@@ -71,6 +75,11 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
     const int cand = lane & 15;
     const int filter = cand / 3;
     c.which = cand - filter * 3;
+    {
+        const int group = lane - c.which;          // cand 15 (no filter) pairs with lanes past its row: it is never valid
+        c.peer_a = ((group + (c.which + 1) % 3) & 63) * 4;
+        c.peer_b = ((group + (c.which + 2) % 3) & 63) * 4;
+    }
     c.live = filter < filter_count;
     c.f = c.live ? filter : 0;
     // taps in 1/64 units (adpcm.c:36-37)
@@ -92,16 +101,24 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
 // loop is kept rolled (codes parked in LDS) so that the whole encoder needs few registers.
 __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, bool unit_live, int lane, int& prev1,
                                             int& prev2, uint32_t& header, uint32_t* pk_lds /* [7][64] per wavefront */) {
-    // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples
+    // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples, so only the first two
+    //      residuals depend on the decoded state and the 28 samples can be split: the three lanes of a filter (one per
+    //      candidate shift) take samples 0..9, 10..18 and 19..27 and share their extremes afterwards.
     int lo = 0, hi = 0;
     {
-        int p1 = prev1, p2 = prev2;
-#pragma unroll 4
-        for (int i = 0; i < 28; i++) {
-            const int xi = xs[i];
+        const int i0 = cd.which == 0 ? 0 : (cd.which == 1 ? 10 : 19);
+        int p1 = i0 ? xs[i0 - 1] : prev1, p2 = i0 ? xs[i0 - 2] : prev2;
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const int xi = xs[i0 + t];             // (which == 2, t == 9 reads padding slot 28; that residual is not used)
             const int r = xi - predict(cd.k1, cd.k2, p1, p2);
-            lo = r < lo ? r : lo;
-            hi = r > hi ? r : hi;
+            if (t < 9) {
+                lo = r < lo ? r : lo;
+                hi = r > hi ? r : hi;
+            } else {
+                lo = (cd.which == 0 && r < lo) ? r : lo;
+                hi = (cd.which == 0 && r > hi) ? r : hi;
+            }
             p2 = p1;
             p1 = xi;
         }
@@ -110,7 +127,13 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
     // -2^(15 - range) both say "bit length of max(hi, ~lo) minus rs is at most 15 - range" (hi >= 0 >= lo), so
     // rs = clamp(bit_length(max(hi, ~lo)) - (15 - range), 0, range); tests/test_adpcm_oracle.py checks it against the loops.
     // (As loops they compiled to ~200 instructions of lane-divergent control flow per unit.)
-    const int widest = hi > ~lo ? hi : ~lo;
+    int widest = hi > ~lo ? hi : ~lo;
+    {
+        // ... of all three lanes of the filter
+        const int a = __builtin_amdgcn_ds_bpermute(cd.peer_a, widest), b = __builtin_amdgcn_ds_bpermute(cd.peer_b, widest);
+        widest = widest > a ? widest : a;
+        widest = widest > b ? widest : b;
+    }
     int rs = (widest > 0 ? 32 - __clz(widest) : 0) - (15 - cd.range);
     rs = rs < 0 ? 0 : (rs > cd.range ? cd.range : rs);
     const int m = cd.range - rs;
