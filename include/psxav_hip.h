@@ -51,7 +51,7 @@ typedef struct psxhip_mdec_ctx psxhip_mdec_ctx_t;
  * width/height: multiples of 16 (psxavenc/mdec.c:601-602), at most 1024 each.
  * max_frame_size: largest per-frame byte budget that will be passed (sizes the LDS staging).
  * A frame's working set (budget + min(budget, 8 KiB) + ~30 bytes per macroblock + ~37 KiB) must fit the CU's 160 KiB
- * LDS, else PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to 78 540-byte budgets;
+ * LDS, else PSXHIP_EINVAL: e.g. 640x512 (the reference CLI's maximum, args.c:410-421) works up to 84 668-byte budgets;
  * psxhip_mdec_query_geometry() tells before creating a context. */
 int psxhip_mdec_create(psxhip_mdec_ctx_t **ctx, int device, int codec, int width, int height,
                        int max_frame_size);
@@ -92,7 +92,7 @@ const char *psxhip_mdec_kernel_name(void);
 /* What a geometry costs, before creating a context for it.  A frame's working set lives in the CU's
  * 160 KiB LDS: the macroblock staging area (max_frame_size) + the frame image (whole, or one 8 KiB tile at a time when
  * that is what fits) + ~30 bytes per macroblock + ~37 KiB (two workgroups per CU when twice that fits, else one).  fits == 0 means psxhip_mdec_create would return PSXHIP_EINVAL; max_frame_size_limit
- * is the largest budget this frame size supports (320x240: 103 516 bytes, 640x480: 80 572, 640x512: 78 540). */
+ * is the largest budget this frame size supports (320x240: 109 644 bytes, 640x480: 86 700, 640x512: 84 668). */
 typedef struct {
 	int32_t fits;
 	int32_t groups_per_cu;          /* frames in flight per compute unit (2 or 1) */

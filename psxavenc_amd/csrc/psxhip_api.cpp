@@ -102,13 +102,36 @@ int mdec_geometry(int width, int height, int max_frame_size, size_t lds_cu, int*
     const int image = (max_frame_size + 3) / 4;     // dwords of the frame image
     const int sw = image + nmb + 2;
     if (sw > 0xFFFF) return 0;                      // staging offsets are 16-bit
-    // the frame image is assembled in LDS either whole or one 8 KiB tile at a time (+2: tile slack).  Whole is a little
-    // faster (one merge sweep) and is taken whenever it costs neither the fit nor the two-groups-per-CU shape.
-    const int ow_tiled = (image < 2048 ? image : 2048) + 2, ow_whole = image + 2;
-    int lg = 2 * psxhip_mdec_lds_bytes(nmb, ow_tiled, sw, 0) > lds_cu;
-    if (const char* e = getenv("PSXHIP_MDEC_LARGE")) { if (atoi(e)) lg = 1; }   // experiments
-    int ow = ow_tiled;
-    if ((lg ? 1 : 2) * psxhip_mdec_lds_bytes(nmb, ow_whole, sw, lg) <= lds_cu) ow = ow_whole;
+    // The frame image is assembled in LDS whole, or one tile of 8 / 4 / 2 KiB at a time (+2: tile slack; at most 16 tiles).
+    // Whole is a little faster (one merge sweep); a smaller tile is taken when that is what lets two 12-wavefront groups
+    // share a CU (17-21 % faster than one 16-wavefront group: 640x480 at 8 KiB budgets needs the 4 KiB tile for it), or
+    // what makes the geometry fit at all.
+    const int tiles[4] = {image, 2048, 1024, 512};
+    int lg = 1, ow = 0;
+    for (int shape = 0; shape < 2 && !ow; shape++) {             // 0: two small groups per CU, 1: one large group
+        for (int i = 0; i < 4 && !ow; i++) {
+            const int t = tiles[i] < image ? tiles[i] : image;
+            if ((image + t - 1) / t > 16) continue;
+            if ((shape ? 1 : 2) * psxhip_mdec_lds_bytes(nmb, t + 2, sw, shape) <= lds_cu) {
+                lg = shape;
+                ow = t + 2;
+            }
+        }
+    }
+    if (const char* e = getenv("PSXHIP_MDEC_LARGE")) {           // experiments: force the large shape
+        if (atoi(e) && !lg) {
+            lg = 1;
+            ow = 0;
+            for (int i = 0; i < 4 && !ow; i++) {
+                const int t = tiles[i] < image ? tiles[i] : image;
+                if ((image + t - 1) / t <= 16 && psxhip_mdec_lds_bytes(nmb, t + 2, sw, 1) <= lds_cu) ow = t + 2;
+            }
+        }
+    }
+    if (!ow) {                                                   // nothing fits: report what the smallest working set would need
+        lg = 1;
+        ow = (image < 512 ? image : 512) + 2;
+    }
     const size_t need = psxhip_mdec_lds_bytes(nmb, ow, sw, lg);
     if (large) *large = lg;
     if (out_words) *out_words = ow;
