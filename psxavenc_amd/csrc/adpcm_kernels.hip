@@ -453,6 +453,11 @@ struct XaJob {
 
 __device__ __forceinline__ uint8_t to_bcd(int v) { return (uint8_t)(v + (v / 10) * 6); }
 
+// EDC tables, the same for every sector: built once on the host (xa_tables()), copied into LDS by every workgroup.
+//   [0..255]    reflected CRC-32 table for polynomial 0xD8018001 (cdrom.c:28-41)
+//   [256 + 32 k + b]  CRC state (1 << b) advanced over 10 * 2^k zero bytes, k = 0..7
+__constant__ uint32_t c_xa_tables[256 + 8 * 32];
+
 __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
     __shared__ __attribute__((aligned(16))) uint8_t sec[2352];
     __shared__ uint32_t crc_tab[256];
@@ -464,30 +469,10 @@ __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
     const int upg = four ? 8 : 4;                 // sound units per group
     const int sector_size = job.format == 0 ? 2336 : 2352;
 
-    // reflected CRC-32 table for polynomial 0xD8018001 (cdrom.c:28-41)
-    {
-        uint32_t v = (uint32_t)tid;
-        for (int k = 0; k < 8; k++) v = (v >> 1) ^ ((v & 1u) ? 0xD8018001u : 0u);
-        crc_tab[tid] = v;
-    }
+    crc_tab[tid] = c_xa_tables[tid];
+    ((uint32_t*)zmat)[tid] = c_xa_tables[256 + tid];
     for (int i = tid; i < 2352 / 4; i += 256) ((uint32_t*)sec)[i] = 0u;
     __syncthreads();
-    if (tid < 32) {
-        uint32_t v = 1u << tid;
-        for (int i = 0; i < 10; i++) v = (v >> 8) ^ crc_tab[v & 0xFF];
-        zmat[0][tid] = v;
-    }
-    __syncthreads();
-    for (int k = 1; k < 8; k++) {
-        if (tid < 32) {
-            const uint32_t v = zmat[k - 1][tid];
-            uint32_t r = 0;
-            for (int bit = 0; bit < 32; bit++)
-                if ((v >> bit) & 1u) r ^= zmat[k - 1][bit];
-            zmat[k][tid] = r;
-        }
-        __syncthreads();
-    }
 
     if (tid == 0) {
         if (job.format == 1) {       // psx_cdrom_init_sector, mode 2 (cdrom.c:55-74)
@@ -883,6 +868,38 @@ extern "C" int psxhip_spu_pack_device(int device, const uint8_t* d_units, int n_
     return PSXHIP_OK;
 }
 
+// builds c_xa_tables on the host and uploads it, once per device
+static int xa_tables(int device) {
+    static bool done[64] = {false};
+    if (device >= 0 && device < 64 && done[device]) return PSXHIP_OK;
+    uint32_t t[256 + 8 * 32];
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t v = i;
+        for (int k = 0; k < 8; k++) v = (v >> 1) ^ ((v & 1u) ? 0xD8018001u : 0u);
+        t[i] = v;
+    }
+    uint32_t* z = t + 256;
+    for (int b = 0; b < 32; b++) {
+        uint32_t v = 1u << b;
+        for (int i = 0; i < 10; i++) v = (v >> 8) ^ t[v & 0xFF];
+        z[b] = v;
+    }
+    for (int k = 1; k < 8; k++)
+        for (int b = 0; b < 32; b++) {
+            const uint32_t v = z[32 * (k - 1) + b];
+            uint32_t r = 0;
+            for (int bit = 0; bit < 32; bit++)
+                if ((v >> bit) & 1u) r ^= z[32 * (k - 1) + bit];
+            z[32 * k + b] = r;
+        }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_xa_tables), t, sizeof t) != hipSuccess) {
+        psxhip_set_error("xa_assemble: table upload failed");
+        return PSXHIP_EDEVICE;
+    }
+    if (device >= 0 && device < 64) done[device] = true;
+    return PSXHIP_OK;
+}
+
 extern "C" int psxhip_xa_assemble_device(int device, const uint8_t* d_units, int n_sectors, int format, int stereo,
                                          int frequency, int bits, int file_number, int channel_number, int first_lba,
                                          const uint8_t* d_eof_flags, uint8_t* d_out, void* stream) {
@@ -894,6 +911,8 @@ extern "C" int psxhip_xa_assemble_device(int device, const uint8_t* d_units, int
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
     if (n_sectors == 0) return PSXHIP_OK;
+    rc = xa_tables(device);
+    if (rc) return rc;
     XaJob job;
     job.units = d_units;
     job.n_sectors = n_sectors;
