@@ -110,10 +110,10 @@ def _profile_traffic(key):
             idx = json.load(fh)
         e = idx.get(key)
         if e:
-            return e["traffic_bytes_per_launch"], e["source"]
+            return e["traffic_bytes_per_launch"], e["source"], e
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def _cpu_baseline_mdec(O, codec, w, h, budget, frames, seconds):
@@ -257,7 +257,17 @@ def main():
 
     version = _lib.lib().psxhip_version().decode()
     wl_key = "sbs codec=%d %dx%d budget=%d frames=%d amp=%d | %s" % (args.codec, w, h, budget, n, args.amp, version)
-    traffic, traffic_src = _profile_traffic(wl_key)
+    traffic, traffic_src, pmc = _profile_traffic(wl_key)
+    # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds its SIMD's issue slot for 4 cycles;
+    # instructions per launch come from the same committed PMC pass as the traffic (SQ_INSTS_VALU).
+    issue = None
+    if pmc and pmc.get("valu_insts_per_launch"):
+        simds, clock_ghz = 256 * 4, 2.4
+        slots = simds * clock_ghz * 1e9 / 4.0 * (kstat["mean"] * 1e-3)
+        issue = {"valu_insts_per_launch": pmc["valu_insts_per_launch"], "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
+                 "lds_insts_per_launch": pmc.get("lds_insts_per_launch"),
+                 "valu_issue_slots_per_launch": int(slots), "valu_busy_frac": round(pmc["valu_insts_per_launch"] / slots, 4),
+                 "note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x this run's mean kernel time; counters from " + str(traffic_src)}
 
     total_frames = n * world * args.steps * lps
     value = total_frames / elapsed
@@ -293,7 +303,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
-                         "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": alg_bytes, "issue": issue,
                          **({"note": "launches of %d contexts overlap: achieved = algorithmic bytes of all launches / elapsed; kernel_ms are "
                                      "per-launch durations while sharing the GPU" % ns} if ns > 1 else {})},
             "cpu_baseline": cpu_baseline,
