@@ -263,7 +263,8 @@ def main():
     issue = None
     if pmc and pmc.get("valu_insts_per_launch"):
         simds, clock_ghz = 256 * 4, 2.4
-        slots = simds * clock_ghz * 1e9 / 4.0 * (kstat["mean"] * 1e-3)
+        eff_ms = kstat["mean"] if max(1, args.streams) == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock
+        slots = simds * clock_ghz * 1e9 / 4.0 * (eff_ms * 1e-3)
         issue = {"valu_insts_per_launch": pmc["valu_insts_per_launch"], "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
                  "lds_insts_per_launch": pmc.get("lds_insts_per_launch"),
                  "valu_issue_slots_per_launch": int(slots), "valu_busy_frac": round(pmc["valu_insts_per_launch"] / slots, 4),
