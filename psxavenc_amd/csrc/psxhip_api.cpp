@@ -79,6 +79,8 @@ struct psxhip_mdec_ctx {
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
     uint32_t* d_order;              // the order a pass's tickets visit the macroblocks (psxhip_mdec_pass_order)
+    uint32_t* d_order_large;        // ... for the 16-wavefront shape, when small batches may use it (see encode_frames_device)
+    int n_cu;
     // host-path staging: two chunk-sized sets of device buffers and pinned host buffers (double buffering)
     hipStream_t stream;
     uint8_t* d_frames[2];
@@ -223,13 +225,19 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), PSXHIP_EDEVICE);
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->kernel_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
-    {
-        const int n = psxhip_mdec_pass_order(width, height, c->large, nullptr, 0);
+    c->n_cu = prop.multiProcessorCount;
+    // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
+    // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
+    // of all.  Needs that shape's pass order too, and its (larger) LDS working set to fit.
+    const bool both = !c->large && psxhip_mdec_lds_bytes(c->nmb, c->out_words, c->stg_words, 1) <= lds_cu && !getenv("PSXHIP_MDEC_NO_SMALL_BATCH_SHAPE");
+    for (int shape = c->large; shape <= (both ? 1 : c->large); shape++) {
+        const int n = psxhip_mdec_pass_order(width, height, shape, nullptr, 0);
         uint32_t* h = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
         if (!h) { psxhip_set_error("out of host memory"); return PSXHIP_ENOMEM; }
-        (void)psxhip_mdec_pass_order(width, height, c->large, h, n);
-        hipError_t e = hipMalloc((void**)&c->d_order, (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(c->d_order, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        (void)psxhip_mdec_pass_order(width, height, shape, h, n);
+        uint32_t** dst = shape == c->large ? &c->d_order : &c->d_order_large;
+        hipError_t e = hipMalloc((void**)dst, (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(*dst, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
         free(h);
         if (e != hipSuccess) { psxhip_set_error("pass order table: %s", hipGetErrorString(e)); return PSXHIP_ENOMEM; }
     }
@@ -253,6 +261,7 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_order) (void)hipFree(c->d_order);
+    if (c->d_order_large) (void)hipFree(c->d_order_large);
     if (c->d_stats) (void)hipFree(c->d_stats);
     psxhip_mdec_free_staging(c);
     for (int b = 0; b < 2; b++)
@@ -302,11 +311,12 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.out_tile = c->out_words - 2;
     a.max_frame_size = c->max_frame_size;
     a.stg_words = c->stg_words;
+    const bool small_batch = c->d_order_large && n_frames <= c->n_cu;
     a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
-    a.large = c->large;
+    a.large = c->large || small_batch;
     a.stream = stream;
     a.d_ticket = c->d_ticket;
-    a.d_order = c->d_order;
+    a.d_order = small_batch ? c->d_order_large : c->d_order;
     a.d_stats = c->d_stats;
     a.prio_pattern = c->prio_pattern;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);

@@ -6,7 +6,7 @@ from psxavenc_amd import synth
 from psxavenc_amd.mdec import MdecEncoder
 w, h, budget = 320, 240, 8192
 enc = MdecEncoder(0, w, h, max_frame_size=budget, device=0)
-for n in (256, 512, 768, 1000, 1024, 1536, 2048, 4096, 8192):
+for n in (1, 64, 256, 300, 512, 768, 1000, 1024, 1536, 2048, 4096, 8192):
     d = synth.frames_device(w, h, 1, 0, n, 4, device=0)
     out = torch.zeros((n, budget), dtype=torch.uint8, device="cuda")
     res = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
