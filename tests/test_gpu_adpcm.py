@@ -395,3 +395,32 @@ def test_spu_strided_input_is_not_read_past_its_last_sample():
     libc.mprotect(base + 3 * page, page, 3)
     del view
     m.close()
+
+
+def test_extreme_signals_where_most_candidates_saturate():
+    """Full-scale alternations, rails and spikes: most (filter, shift) candidates clip and their squared error passes 2^32.
+    The kernel sums the error in 32 bits with saturation -- exact for the arg-min because filter 0 at its minimum shift
+    never clips -- and computes the minimum shift in closed form; every byte must still equal the oracle (SPU: 5 filters,
+    XA 4-bit and 8-bit)."""
+    from psxavenc_amd import adpcm
+    rng = np.random.default_rng(77)
+    n = 28 * 600
+    sigs = [
+        np.where(np.arange(n) % 2 == 0, 32767, -32768),
+        np.where((np.arange(n) // 3) % 2 == 0, 32767, -32768),
+        np.where((np.arange(n) // 28) % 2 == 0, -32768, 32767),
+        rng.choice(np.array([-32768, -1, 0, 1, 32767]), n),
+        np.where(rng.random(n) < 0.05, rng.choice(np.array([-32768, 32767]), n), rng.integers(-40, 40, n)),
+        np.full(n, -32768), np.full(n, 32767),
+    ]
+    for k, sig in enumerate(sigs):
+        pcm = sig.astype(np.int16)
+        want, _ = O.spu_encode(pcm)
+        got = adpcm.spu_encode_streams(pcm[None, :], sample_count=n)[0][:want.size]
+        assert np.array_equal(got, want), ("spu", k)
+        for bits in (4, 8):
+            s, so = adpcm.XaSettings(1, False, 37800, bits, 0, 0), O.XaSettings(1, 0, 37800, bits, 0, 0)
+            padded = np.concatenate([pcm, np.zeros(8064, np.int16)])
+            want, _ = O.xa_encode(so, padded, n, lba=3)
+            got = adpcm.xa_encode_streams(s, padded[None, :], n, lbas=np.array([3], np.int32))[0]
+            assert got.size == want.size and np.array_equal(got, want), ("xa", bits, k)
