@@ -658,7 +658,7 @@ struct psxhip_adpcm_session {
     bool speculated;
     hipStream_t stream;
     ChunkJob job;
-    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_changed, d_cstates, d_lead, d_final, d_known;
+    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_cstates, d_lead, d_final, d_known;
 };
 
 #define TRY(expr)                                                                                   \
@@ -719,7 +719,6 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     if (e == hipSuccess) e = s->d_cfirst.alloc(sizeof(int32_t) * nk);
     if (e == hipSuccess) e = s->d_used.alloc(sizeof(psxhip_adpcm_state_t) * nk);
     if (e == hipSuccess) e = s->d_ustates.alloc(sizeof(psxhip_adpcm_state_t) * (size_t)(total_units ? total_units : 1));
-    if (e == hipSuccess) e = s->d_changed.alloc(sizeof(int));
     if (e != hipSuccess) {
         psxhip_set_error("adpcm_session_create: hipMalloc failed: %s", hipGetErrorString(e));
         return PSXHIP_ENOMEM;
@@ -755,7 +754,7 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     job.unit_states = s->d_ustates.as<psxhip_adpcm_state_t>();
     job.start_used = s->d_used.as<psxhip_adpcm_state_t>();
     job.units = d_units;
-    job.changed = s->d_changed.as<int>();
+    job.changed = nullptr;      // set by session_run: the running thread's flag word
     guard.p = nullptr;                   // ownership passes to the caller
     *out = s;
     return PSXHIP_OK;
@@ -788,6 +787,16 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
     else TRY(hipMemsetAsync(s->d_known.p, 1, (size_t)s->n_chains, st));
     int passes = 0;
     if (s->n_chunks) {
+        // "some chunk's start state changed" is a word of page-locked host memory the verify kernel raises and the host reads
+        // after the stream synchronise: no memset / copy per pass, nothing queued on a copy engine that may be busy with
+        // somebody else's frames.  One word per host thread (a run is synchronous).
+        static thread_local int* flag = nullptr;
+        if (!flag && hipHostMalloc((void**)&flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            flag = nullptr;
+            psxhip_set_error("adpcm_session_run: no page-locked memory for the verify flag");
+            return PSXHIP_ENOMEM;
+        }
+        s->job.changed = flag;
         const dim3 grid((unsigned)((s->n_chunks + 3) / 4)), block(64);
         if (!s->speculated) {
             hipLaunchKernelGGL(adpcm_chunks_kernel<false>, grid, block, 0, st, s->job);
@@ -796,12 +805,11 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
             if (any_change) *any_change = 1;
         }
         for (;;) {
-            TRY(hipMemsetAsync(s->d_changed.p, 0, sizeof(int), st));
+            *(volatile int*)flag = 0;      // (no verify kernel is in flight here: the previous pass ended with a synchronise)
             hipLaunchKernelGGL(adpcm_chunks_kernel<true>, grid, block, 0, st, s->job);
             TRY(hipGetLastError());
-            int changed = 0;
-            TRY(hipMemcpyAsync(&changed, s->d_changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
             TRY(hipStreamSynchronize(st));
+            const int changed = *(volatile int*)flag;
             passes++;
             if (!changed) break;
             if (any_change) *any_change = 1;
