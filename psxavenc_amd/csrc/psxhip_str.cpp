@@ -191,58 +191,14 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
     std::vector<psxhip_mdec_result_t> res((size_t)n_frames);
     int rc_video = PSXHIP_OK;
     char err_video[256] = "";
-    std::thread video([&]() {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        const int key[5] = {device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size};
-        if (!g_ctx || memcmp(key, g_ctx_key, sizeof key) != 0) {
-            psxhip_mdec_destroy(g_ctx);
-            g_ctx = nullptr;
-            rc_video = psxhip_mdec_create(&g_ctx, device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size);
-            if (rc_video == PSXHIP_OK) memcpy(g_ctx_key, key, sizeof key);
-        }
-        if (rc_video == PSXHIP_OK)
-            rc_video = psxhip_mdec_encode_frames_host(g_ctx, frames, n_frames, pl.budgets.data(), 0, bs, ostride, res.data());
-        if (rc_video) snprintf(err_video, sizeof err_video, "%s", psxhip_last_error());     // thread-local text
-    });
-
-    // ---- audio: one XA stream, concurrently
-    const int na = pl.pub.n_audio_sectors, sps = pl.pub.audio_samples_per_sector, ch = s->audio_channels;
     std::vector<uint8_t> xa_out;
-    int rc_audio = PSXHIP_OK;
-    if (na > 0) {
-        // the reference relies on zero padding after the end of the PCM data (decoding.c:497-503); a stream whose audio
-        // is shorter than its video gets silence here (the reference writes an uninitialised sector, filefmt.c:476-490)
-        const int64_t need = (int64_t)na * sps;
-        std::vector<int16_t> padded;
-        const int16_t* src = pcm;
-        if (pcm_samples_per_channel < need) {
-            padded.assign((size_t)need * ch, 0);
-            if (pcm_samples_per_channel) memcpy(padded.data(), pcm, (size_t)pcm_samples_per_channel * ch * sizeof(int16_t));
-            src = padded.data();
-        }
-        xa_out.resize((size_t)na * ssz);
-        psxhip_adpcm_state_t st[2] = {{0, 0}, {0, 0}};
-        const int32_t lba0 = 0;
-        const int fmt = s->format == FORMAT_STRCD ? 1 : 0;
-        rc_audio = psxhip_xa_encode_streams_host(device, fmt, ch == 2, s->audio_frequency, s->audio_bit_depth,
-                                                 s->audio_xa_file, s->audio_xa_channel, src, 1, need * ch, (int)need, &lba0, st,
-                                                 xa_out.data(), (int64_t)xa_out.size(), 1);
-        if (rc_audio > 0) rc_audio = PSXHIP_OK;
-    }
-    video.join();
-    if (rc_video) {
-        psxhip_set_error("psxhip_str_encode_host: video: %s", err_video);
-        return rc_video;
-    }
-    if (rc_audio) return rc_audio;
-
-    // ---- interleave (filefmt.c:450-503)
+    // ---- interleave (filefmt.c:450-503): which frame slice / audio sector lands in which sector is known from the plan alone
     const int at = s->format == FORMAT_STR ? 0x08 : (s->format == FORMAT_STRCD ? 0x18 : 0x00);     // mdec.c:822-829
     // which frame slice / audio sector lands in which sector: a short serial walk; the sectors themselves (2 KiB of copying
     // and a 2 KiB EDC each) are then built by a few threads, each on its own range
     const int ns = pl.pub.n_sectors;
     std::vector<int32_t> sec_frame((size_t)ns), sec_off((size_t)ns);        // video: frame, byte offset; audio: -1, audio sector
-    long long qsum = 0;
+    int frames_in_stream = 0;
     {
         int frame = -1, offset = 0, budget = 0, audio_sector = 0;
         for (int n = 0; n < ns; n++) {
@@ -251,7 +207,6 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
                     frame++;
                     budget = pl.budgets[(size_t)frame];
                     offset = 0;
-                    qsum += res[(size_t)frame].quant_scale;
                 }
                 sec_frame[(size_t)n] = frame;
                 sec_off[(size_t)n] = offset;
@@ -261,12 +216,16 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
                 sec_off[(size_t)n] = audio_sector++;
             }
         }
+        frames_in_stream = frame + 1;
     }
-    auto build = [&](int n0, int n1) {
+    // `video`: build the video sectors of [n0, n1), else its audio sectors -- the two kinds are built by different threads at
+    // different times (whichever of the frame encode and the XA encode finishes first has its sectors cut while the other runs)
+    auto build = [&](int n0, int n1, bool video) {
         uint8_t sector[PSX_CDROM_SECTOR_SIZE];
         for (int n = n0; n < n1; n++) {
             uint8_t* dst = out + (size_t)n * ssz;
             const int frame = sec_frame[(size_t)n], offset = sec_off[(size_t)n];
+            if ((frame >= 0) != video) continue;
             if (frame >= 0) {
                 const int budget = pl.budgets[(size_t)frame];
                 memset(sector, 0, sizeof sector);            // the reference's buffer is an uninitialised stack array
@@ -313,16 +272,66 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
             }
         }
     };
-    {
+    auto build_all = [&](bool video) {
         const unsigned hw = std::thread::hardware_concurrency();
         int nt = ns >= 2048 ? (hw >= 64 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1))) : 1;
+        if (!video && nt > 4) nt = 4;                       // one sector in eight, and no checksum to compute
         std::vector<std::thread> th;
         const int per = (ns + nt - 1) / nt;
         for (int t = 1; t < nt; t++)
-            if (t * per < ns) th.emplace_back(build, t * per, (t + 1) * per < ns ? (t + 1) * per : ns);
-        build(0, per < ns ? per : ns);
+            if (t * per < ns) th.emplace_back(build, t * per, (t + 1) * per < ns ? (t + 1) * per : ns, video);
+        build(0, per < ns ? per : ns, video);
         for (auto& x : th) x.join();
+    };
+
+    std::thread video([&]() {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        const int key[5] = {device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size};
+        if (!g_ctx || memcmp(key, g_ctx_key, sizeof key) != 0) {
+            psxhip_mdec_destroy(g_ctx);
+            g_ctx = nullptr;
+            rc_video = psxhip_mdec_create(&g_ctx, device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size);
+            if (rc_video == PSXHIP_OK) memcpy(g_ctx_key, key, sizeof key);
+        }
+        if (rc_video == PSXHIP_OK)
+            rc_video = psxhip_mdec_encode_frames_host(g_ctx, frames, n_frames, pl.budgets.data(), 0, bs, ostride, res.data());
+        if (rc_video) snprintf(err_video, sizeof err_video, "%s", psxhip_last_error());     // thread-local text
+        else build_all(true);
+    });
+
+    // ---- audio: one XA stream, concurrently
+    const int na = pl.pub.n_audio_sectors, sps = pl.pub.audio_samples_per_sector, ch = s->audio_channels;
+    int rc_audio = PSXHIP_OK;
+    if (na > 0) {
+        // the reference relies on zero padding after the end of the PCM data (decoding.c:497-503); a stream whose audio
+        // is shorter than its video gets silence here (the reference writes an uninitialised sector, filefmt.c:476-490)
+        const int64_t need = (int64_t)na * sps;
+        std::vector<int16_t> padded;
+        const int16_t* src = pcm;
+        if (pcm_samples_per_channel < need) {
+            padded.assign((size_t)need * ch, 0);
+            if (pcm_samples_per_channel) memcpy(padded.data(), pcm, (size_t)pcm_samples_per_channel * ch * sizeof(int16_t));
+            src = padded.data();
+        }
+        xa_out.resize((size_t)na * ssz);
+        psxhip_adpcm_state_t st[2] = {{0, 0}, {0, 0}};
+        const int32_t lba0 = 0;
+        const int fmt = s->format == FORMAT_STRCD ? 1 : 0;
+        rc_audio = psxhip_xa_encode_streams_host(device, fmt, ch == 2, s->audio_frequency, s->audio_bit_depth,
+                                                 s->audio_xa_file, s->audio_xa_channel, src, 1, need * ch, (int)need, &lba0, st,
+                                                 xa_out.data(), (int64_t)xa_out.size(), 1);
+        if (rc_audio > 0) rc_audio = PSXHIP_OK;
     }
+    if (rc_audio == PSXHIP_OK && na > 0) build_all(false);
+    video.join();
+    if (rc_video) {
+        psxhip_set_error("psxhip_str_encode_host: video: %s", err_video);
+        return rc_video;
+    }
+    if (rc_audio) return rc_audio;
+
+    long long qsum = 0;
+    for (int f = 0; f < frames_in_stream; f++) qsum += res[(size_t)f].quant_scale;
     pl.pub.quant_scale_sum = qsum;
     if (plan_out) *plan_out = pl.pub;
     return PSXHIP_OK;
