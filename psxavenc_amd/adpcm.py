@@ -254,7 +254,7 @@ def pick_chunking(total_units):
     p = 64
     while p * 2 <= c and p < 1024:
         p *= 2
-    return p, min(64, max(16, p // 8))
+    return p, (32 if p >= 1024 else 16)
 
 
 class AdpcmSession:

@@ -25,14 +25,13 @@ namespace {
 constexpr int kChunkedThreshold = 4096;
 
 // chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass), short enough
-// that there are >= ~16 k chunks to fill 256 CUs (tools/gpu_adpcm_sweep.py); warm-up = chunk / 8
+// that there are >= ~16 k chunks to fill 256 CUs (tools/gpu_adpcm_sweep.py); warm-up 16 or 32 units
 inline void pick_chunking(long long total_units, int* chunk_units, int* warmup_units) {
     long long c = total_units / 16384;
     int p = 64;
     while (p * 2 <= c && p < 1024) p *= 2;
     *chunk_units = p;
-    int w = p / 8;
-    *warmup_units = w < 16 ? 16 : (w > 64 ? 64 : w);
+    *warmup_units = p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 64 either
 }
 
 // Device scratch of the host-buffer entry points.  The reference calls psx_audio_spu_encode once per 28 samples and

@@ -10,7 +10,7 @@ for kind in (0, 2):
         synth.pcm_device(5, c, 0, n, kind, out=d[c])
     chains = adpcm.make_chains(np.arange(n_chains) * n, 1, n, n_units)
     base = np.arange(n_chains, dtype=np.int32) * n_units
-    for chunk, warm in ((128, 32), (256, 32), (256, 64), (512, 64), (1024, 64), (2048, 128)):
+    for chunk, warm in ((256, 16), (256, 32), (512, 16), (512, 32), (512, 64), (1024, 16), (1024, 32), (1024, 64)):
         adpcm.encode_chains_device(d.reshape(-1), chains, base, 4, 4, chunk_units=chunk, warmup_units=warm)
         torch.cuda.synchronize(); t = time.perf_counter()
         u, s, passes = adpcm.encode_chains_device(d.reshape(-1), chains, base, 4, 4, chunk_units=chunk, warmup_units=warm)
