@@ -120,11 +120,11 @@ PSX_HD int mdec_search_predict(const MdecSearch& s, int guess, int room, int fix
 // macroblocks done so far (0 = that scale is not part of the pass).  Returns 0 to carry on, or a new guess when the
 // projection is clearly (margin_permille of the AC room) on the wrong side: the emit scale will not fit, or the count
 // scale fits already.  Projections never enter the search state -- they only steer.
-PSX_HD int mdec_search_checkpoint(const MdecSearch& s, int a, int pa, int b, int pb, int limit_bits, int fixed_bits,
-                                  int margin_permille) {
+// (`margin` in bits: how far a projection has to be on the wrong side)
+PSX_HD int mdec_search_checkpoint_bits(const MdecSearch& s, int a, int pa, int b, int pb, int limit_bits, int fixed_bits,
+                                       int margin) {
     const int room = limit_bits - fixed_bits;
     if (room <= 0) return 0;
-    const int margin = (int)((long long)room * margin_permille / 1000);
     const bool too_low = b && pb > limit_bits + margin;       // the stream being built will not fit
     const bool too_high = a && pa <= limit_bits - margin;     // the scale below it fits as well
     if (!too_low && !too_high) return 0;
@@ -139,6 +139,14 @@ PSX_HD int mdec_search_checkpoint(const MdecSearch& s, int a, int pa, int b, int
     if (g < 1) g = 1;
     if (g > 63) g = 63;
     return g == cur ? 0 : g;
+}
+
+// ... with the margin given in permille of the AC room
+PSX_HD int mdec_search_checkpoint(const MdecSearch& s, int a, int pa, int b, int pb, int limit_bits, int fixed_bits,
+                                  int margin_permille) {
+    const int room = limit_bits - fixed_bits;
+    if (room <= 0) return 0;
+    return mdec_search_checkpoint_bits(s, a, pa, b, pb, limit_bits, fixed_bits, (int)((long long)room * margin_permille / 1000));
 }
 
 // what to do next.  `guess` = predicted answer (used until something has been evaluated), `fixed_bits` = the

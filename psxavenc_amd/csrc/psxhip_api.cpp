@@ -78,6 +78,7 @@ struct psxhip_mdec_ctx {
     unsigned int* d_ticket;         // [2] frame hand-out counters (the kernel re-arms them when it ends)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
+    int ck_margin;
     uint32_t* d_order;              // the order a pass's tickets visit the macroblocks (psxhip_mdec_pass_order)
     uint32_t* d_order_large;        // ... for the 16-wavefront shape, when small batches may use it (see encode_frames_device)
     int n_cu;
@@ -219,6 +220,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     if (const char* e = getenv("PSXHIP_MDEC_GRID")) { const int g = atoi(e); if (g > 0 && g < c->groups_max) c->groups_max = g; }   // experiments
     c->prio_pattern = 0x2FE01u;
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
 
     HIP_TRY(hipMalloc((void**)&c->d_ticket, 4 * sizeof(unsigned int)), PSXHIP_ENOMEM);
     HIP_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned int)), PSXHIP_EDEVICE);
@@ -319,6 +321,7 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.d_order = small_batch ? c->d_order_large : c->d_order;
     a.d_stats = c->d_stats;
     a.prio_pattern = c->prio_pattern;
+    a.ck_margin = c->ck_margin;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }

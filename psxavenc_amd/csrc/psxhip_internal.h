@@ -7,7 +7,7 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k2.18"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k2.19"
 
 #ifdef __cplusplus
 extern "C" {
@@ -33,6 +33,7 @@ typedef struct {
 	unsigned int *d_ticket;         /* [2] frame hand-out counters, zero between launches */
 	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
 	unsigned prio_pattern;          /* see FrameJob */
+	int ck_margin;                  /* checkpoint margin in thousandths of the projection's standard error (0 = default) */
 	const uint32_t *d_order;        /* psxhip_mdec_pass_order() for this geometry, in device memory */
 } psxhip_mdec_launch_t;
 
