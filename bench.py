@@ -261,7 +261,7 @@ def main():
     # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds its SIMD's issue slot for 4 cycles;
     # instructions per launch come from the same committed PMC pass as the traffic (SQ_INSTS_VALU).
     issue = None
-    if pmc and pmc.get("valu_insts_per_launch"):
+    if pmc and pmc.get("valu_insts_per_launch") and not getattr(args, "share_gpu", False):      # (ranks sharing one GPU: a rank's kernel time is not the GPU's)
         simds, clock_ghz = 256 * 4, 2.4
         eff_ms = kstat["mean"] if max(1, args.streams) == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock
         slots = simds * clock_ghz * 1e9 / 4.0 * (eff_ms * 1e-3)
