@@ -51,6 +51,21 @@ __device__ __forceinline__ uint64_t row_min_u64(uint64_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint64_t bperm64(int addr, uint64_t v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)v), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// maximum over the wavefront (a few times per kernel: loop bounds of rows with different lengths)
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 struct ChainJob {
     const int16_t* samples;
     const psxhip_adpcm_chain_t* chains;
@@ -62,23 +77,34 @@ struct ChainJob {
     uint8_t* units;
 };
 
-// Per-lane constants of the candidate this lane owns inside its 16-lane row.
+// A wavefront's 64 lanes are cut into ROWS of candidates, one chain per row.  SPU has 5 filters x 3 shifts = 15 candidates:
+// 16-lane rows (= DPP rows), 4 chains per wavefront.  XA has 4 filters = 12 candidates: the time-parallel kernel packs
+// 12-lane rows, 5 chains per wavefront (lanes 60..63 idle), a quarter more chains per instruction issued.
+template <int ROW> __device__ __forceinline__ int row_of(int lane) { return ROW == 16 ? lane >> 4 : lane / 12; }
+template <int ROW> __device__ __forceinline__ int col_of(int lane) { return ROW == 16 ? lane & 15 : lane - (lane / 12) * 12; }
+
+// Per-lane constants of the candidate this lane owns inside its row.
 struct Candidate {
     int f, which, k1, k2;
     int peer_a, peer_b;      // byte addresses (lane * 4) of the two other lanes that try this lane's filter
+    int peer_f[3];           // 12-lane rows: the lanes with this lane's shift choice in the three other filters
+    int row_base;            // first lane of this lane's row
     bool live;
     int range, qmin, qmax, qmask, half;
 };
 
+template <int ROW>
 __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, int range) {
     Candidate c;
-    const int cand = lane & 15;
+    const int cand = col_of<ROW>(lane);
     const int filter = cand / 3;
     c.which = cand - filter * 3;
+    c.row_base = lane - cand;
     {
         const int group = lane - c.which;          // cand 15 (no filter) pairs with lanes past its row: it is never valid
         c.peer_a = ((group + (c.which + 1) % 3) & 63) * 4;
         c.peer_b = ((group + (c.which + 2) % 3) & 63) * 4;
+        for (int k = 0; k < 3; k++) c.peer_f[k] = ((c.row_base + (cand + 3 * (k + 1)) % 12) & 63) * 4;
     }
     c.live = filter < filter_count;
     c.f = c.live ? filter : 0;
@@ -99,6 +125,7 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
 // (prev1, prev2) advance to the winner's decoded state when `unit_live`.  Returns true on the winning lane,
 // whose `header` and pk_lds[w * 64 + lane] (w = 0..6: four codes per word) then hold the unit's record.  The trial
 // loop is kept rolled (codes parked in LDS) so that the whole encoder needs few registers.
+template <int ROW>
 __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, bool unit_live, int lane, int& prev1,
                                             int& prev2, uint32_t& header, uint32_t* pk_lds /* [7][64] per wavefront */) {
     // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples, so only the first two
@@ -181,10 +208,23 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
 
     // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
     const uint64_t key = valid ? (((uint64_t)sse << 8) | ((uint64_t)cd.f << 4) | (uint64_t)sh) : ~0ull;
-    const uint64_t best = row_min_u64(key);
+    uint64_t best;
+    if (ROW == 16) {
+        best = row_min_u64(key);
+    } else {
+        // 12-lane rows do not coincide with DPP rows: first the three lanes of a filter, then the four filters
+        best = key;
+        uint64_t o;
+        o = bperm64(cd.peer_a, best); best = o < best ? o : best;
+        o = bperm64(cd.peer_b, key); best = o < best ? o : best;
+        const uint64_t mine = best;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o = bperm64(cd.peer_f[k], mine); best = o < best ? o : best; }
+    }
     const bool winner = valid && key == best;
     const uint64_t wmask = __ballot(winner);
-    const int wlane = (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48);
+    const int wlane = ROW == 16 ? (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48)
+                                : (int)__builtin_ctzll(((wmask >> cd.row_base) & 0xFFFull) | 0x1000ull) + cd.row_base;
     header = (uint32_t)((sh & 0x0F) | (cd.f << 4));
     const int np1 = __shfl(p1, wlane & 63, 64);
     const int np2 = __shfl(p2, wlane & 63, 64);
@@ -205,21 +245,30 @@ __device__ __forceinline__ void wave_sync() {
 // 32-int buffer): lane c of the row fetches samples c and c + 16.  Samples at chain index >= sample_limit read
 // as zero without touching memory (adpcm.c:65,110).
 struct UnitFetch {
-    int a, b;
+    int a, b, c;
 };
+template <int ROW>
 __device__ __forceinline__ UnitFetch fetch_unit(const int16_t* src, const psxhip_adpcm_chain_t& ch, int u, bool live, int lane) {
-    const int c = lane & 15;
+    const int c = col_of<ROW>(lane);
     const int limit = ch.sample_limit - u * 28;
     UnitFetch f;
     f.a = (live && c < limit) ? (int)src[(long long)(u * 28 + c) * ch.pitch] : 0;
-    f.b = (live && c + 16 < 28 && c + 16 < limit) ? (int)src[(long long)(u * 28 + c + 16) * ch.pitch] : 0;
+    f.b = (live && c + ROW < 28 && c + ROW < limit) ? (int)src[(long long)(u * 28 + c + ROW) * ch.pitch] : 0;
+    f.c = 0;
+    if (ROW == 12) f.c = (live && c + 24 < 28 && c + 24 < limit) ? (int)src[(long long)(u * 28 + c + 24) * ch.pitch] : 0;
     return f;
 }
+template <int ROW>
 __device__ __forceinline__ void stage_unit(int* xs, const UnitFetch& f, int lane) {
-    const int c = lane & 15;
+    const int c = col_of<ROW>(lane);
     wave_sync();            // the previous unit's readers are done
     xs[c] = f.a;
-    xs[c + 16] = f.b;       // slots 28..31 are padding
+    if (ROW == 16) {
+        xs[c + 16] = f.b;   // slots 28..31 are padding
+    } else {
+        xs[c + 12] = f.b;
+        if (c < 8) xs[c + 24] = f.c;       // samples 24..27, padding 28..31
+    }
     wave_sync();
 }
 
@@ -234,7 +283,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job)
     const int lane = (int)(threadIdx.x & 63);
     const int chain = (int)blockIdx.x * 4 + (lane >> 4);
     const bool chain_live = chain < job.n_chains;
-    const Candidate cd = make_candidate(lane, job.filter_count, job.range);
+    const Candidate cd = make_candidate<16>(lane, job.filter_count, job.range);
 
     psxhip_adpcm_chain_t ch;
     ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
@@ -256,13 +305,13 @@ __global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job)
     __shared__ uint32_t pk_lds[7 * 64];
     int* xs = xs_all[lane >> 4];
 
-    UnitFetch nxt = fetch_unit(src, ch, 0, chain_live && 0 < ch.n_units, lane);
+    UnitFetch nxt = fetch_unit<16>(src, ch, 0, chain_live && 0 < ch.n_units, lane);
     for (int u = 0; u < n_max; u++) {
         const bool unit_live = chain_live && u < ch.n_units;
-        stage_unit(xs, nxt, lane);
-        if (u + 1 < n_max) nxt = fetch_unit(src, ch, u + 1, chain_live && u + 1 < ch.n_units, lane);   // prefetch
+        stage_unit<16>(xs, nxt, lane);
+        if (u + 1 < n_max) nxt = fetch_unit<16>(src, ch, u + 1, chain_live && u + 1 < ch.n_units, lane);   // prefetch
         uint32_t header;
-        if (encode_unit(cd, xs, unit_live, lane, prev1, prev2, header, pk_lds))
+        if (encode_unit<16>(cd, xs, unit_live, lane, prev1, prev2, header, pk_lds))
             store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
     }
     if (chain_live && (lane & 15) == 0) {
@@ -305,12 +354,14 @@ struct ChunkJob {
     int* changed;                    // verify: set to 1 when any chunk had to be re-encoded
 };
 
-template <bool VERIFY>
+template <bool VERIFY, int ROW>
 __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job) {
+    constexpr int kRows = 64 / ROW;            // chains per wavefront: 4 or 5
     const int lane = (int)(threadIdx.x & 63);
-    const int chunk = (int)blockIdx.x * 4 + (lane >> 4);
-    const bool chunk_live = chunk < job.n_chunks;
-    const Candidate cd = make_candidate(lane, job.filter_count, job.range);
+    const int row = row_of<ROW>(lane), col = col_of<ROW>(lane);
+    const int chunk = (int)blockIdx.x * kRows + row;
+    const bool chunk_live = row < kRows && chunk < job.n_chunks;
+    const Candidate cd = make_candidate<ROW>(lane, job.filter_count, job.range);
 
     psxhip_adpcm_chain_t ch;
     ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
@@ -341,7 +392,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
                 active = true;
                 prev1 = truth.prev1;
                 prev2 = truth.prev2;
-                if ((lane & 15) == 0) {
+                if (col == 0) {
                     job.start_used[chunk] = truth;
                     *job.changed = 1;
                 }
@@ -353,18 +404,17 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     // ---- warm-up (speculate only): advance the state, keep nothing
     int n_warm = active ? warm : 0;
     int w_max = n_warm;
-    w_max = max(w_max, __shfl_xor(w_max, 16, 64));
-    w_max = max(w_max, __shfl_xor(w_max, 32, 64));
-    __shared__ int xs_all[4][32];
+    w_max = wave_max(w_max);
+    __shared__ int xs_all[64 / ROW + 1][32];
     __shared__ uint32_t pk_lds[7 * 64];
-    int* xs = xs_all[lane >> 4];
+    int* xs = xs_all[row];
     for (int t = 0; t < w_max; t++) {
         const bool live = t < n_warm;
-        stage_unit(xs, fetch_unit(src, ch, first - n_warm + t, live, lane), lane);
+        stage_unit<ROW>(xs, fetch_unit<ROW>(src, ch, first - n_warm + t, live, lane), lane);
         uint32_t header;
-        (void)encode_unit(cd, xs, live, lane, prev1, prev2, header, pk_lds);
+        (void)encode_unit<ROW>(cd, xs, live, lane, prev1, prev2, header, pk_lds);
     }
-    if (!VERIFY && chunk_live && (lane & 15) == 0) {
+    if (!VERIFY && chunk_live && col == 0) {
         psxhip_adpcm_state_t s0;
         s0.prev1 = prev1;
         s0.prev2 = prev2;
@@ -374,22 +424,21 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     // ---- the chunk itself
     int n_run = active ? count : 0;
     int n_max = n_run;
-    n_max = max(n_max, __shfl_xor(n_max, 16, 64));
-    n_max = max(n_max, __shfl_xor(n_max, 32, 64));
+    n_max = wave_max(n_max);
     // Software pipeline: while unit t is encoded, the samples of unit t + 1 and (verify) the state stored for it are on
     // their way; they are staged into the other LDS buffer right after the encode -- by then they have arrived and nothing
     // younger is in flight -- and only then this unit's record and state are stored.  The loop never waits for a store.
     // (Loading the stored state where it is compared cost two exposed global round trips per unit: 2.3 us instead of 1.)
     bool running = active;
-    __shared__ int xs_alt[4][32];
+    __shared__ int xs_alt[64 / ROW + 1][32];
     int* xs_a = xs;
-    int* xs_b = xs_alt[lane >> 4];
-    UnitFetch nxt = fetch_unit(src, ch, first, running && 0 < n_run, lane);
+    int* xs_b = xs_alt[row];
+    UnitFetch nxt = fetch_unit<ROW>(src, ch, first, running && 0 < n_run, lane);
     psxhip_adpcm_state_t old_nxt;
     old_nxt.prev1 = 0;
     old_nxt.prev2 = 0;
     if (VERIFY && running && 0 < n_run) old_nxt = job.unit_states[st0 + first];
-    stage_unit(xs_a, nxt, lane);
+    stage_unit<ROW>(xs_a, nxt, lane);
     for (int t = 0; t < n_max; t++) {
         const bool live = running && t < n_run;
         if (!__any(live)) break;
@@ -398,17 +447,17 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
         const bool more = t + 1 < n_max;
         if (more) {
             const bool nlive = running && t + 1 < n_run;
-            nxt = fetch_unit(src, ch, u + 1, nlive, lane);
+            nxt = fetch_unit<ROW>(src, ch, u + 1, nlive, lane);
             if (VERIFY && nlive) old_nxt = job.unit_states[st0 + u + 1];
         }
         uint32_t header;
-        const bool winner = encode_unit(cd, xs_a, live, lane, prev1, prev2, header, pk_lds);
+        const bool winner = encode_unit<ROW>(cd, xs_a, live, lane, prev1, prev2, header, pk_lds);
         // (verify) coincided with the state stored for this unit: everything after it is already consistent.  The record of
         // THIS unit may still differ (different start, same end), so it is written, then the chunk stops.
         if (VERIFY && live && old.prev1 == prev1 && old.prev2 == prev2) running = false;
-        if (more) stage_unit(xs_b, nxt, lane);
+        if (more) stage_unit<ROW>(xs_b, nxt, lane);
         if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
-        if (live && (lane & 15) == 0) {
+        if (live && col == 0) {
             psxhip_adpcm_state_t s1;
             s1.prev1 = prev1;
             s1.prev2 = prev2;
@@ -797,16 +846,21 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
             return PSXHIP_ENOMEM;
         }
         s->job.changed = flag;
-        const dim3 grid((unsigned)((s->n_chunks + 3) / 4)), block(64);
+        // XA's 4 filters fill 12 of a row's lanes: 12-lane rows, five chunks per wavefront; SPU's 5 filters need 16-lane rows
+        const bool narrow = s->job.filter_count == 4;
+        const int per = narrow ? 5 : 4;
+        const dim3 grid((unsigned)((s->n_chunks + per - 1) / per)), block(64);
         if (!s->speculated) {
-            hipLaunchKernelGGL(adpcm_chunks_kernel<false>, grid, block, 0, st, s->job);
+            if (narrow) hipLaunchKernelGGL((adpcm_chunks_kernel<false, 12>), grid, block, 0, st, s->job);
+            else hipLaunchKernelGGL((adpcm_chunks_kernel<false, 16>), grid, block, 0, st, s->job);
             TRY(hipGetLastError());
             s->speculated = true;
             if (any_change) *any_change = 1;
         }
         for (;;) {
             *(volatile int*)flag = 0;      // (no verify kernel is in flight here: the previous pass ended with a synchronise)
-            hipLaunchKernelGGL(adpcm_chunks_kernel<true>, grid, block, 0, st, s->job);
+            if (narrow) hipLaunchKernelGGL((adpcm_chunks_kernel<true, 12>), grid, block, 0, st, s->job);
+            else hipLaunchKernelGGL((adpcm_chunks_kernel<true, 16>), grid, block, 0, st, s->job);
             TRY(hipGetLastError());
             TRY(hipStreamSynchronize(st));
             const int changed = *(volatile int*)flag;
