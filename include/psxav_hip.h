@@ -119,7 +119,11 @@ int psxhip_mdec_query_geometry(int device, int codec, int width, int height, int
  * checkpoint, end of pass, search step, merge + write-out).  Word 2 of a group's trace record: frames | ticks from group
  * entry to the end of its prologue << 8 | ticks to the end of its first frame << 32. */
 #define PSXHIP_MDEC_STATS_PHASE0 (PSXHIP_MDEC_STATS + 4 * PSXHIP_MDEC_TRACE_GROUPS)
-#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS_PHASE0 + 16)
+/* and one word per frame of the last launch (the first PSXHIP_MDEC_TRACE_FRAMES frames): first guess | first checkpoint
+ * verdict << 8 | answer << 16 | passes << 24 */
+#define PSXHIP_MDEC_TRACE_FRAMES 2048
+#define PSXHIP_MDEC_STATS_FRAME0 (PSXHIP_MDEC_STATS_PHASE0 + 16)
+#define PSXHIP_MDEC_STATS_TOTAL (PSXHIP_MDEC_STATS_FRAME0 + PSXHIP_MDEC_TRACE_FRAMES)
 int psxhip_mdec_read_stats(psxhip_mdec_ctx_t *ctx, unsigned long long *out, int n, int reset);
 
 /* ---------------------------------------------------------------- SPU / XA ADPCM ----------- */

@@ -14,7 +14,7 @@ from psxavenc_amd.mdec import MdecEncoder
 CASES = {
     "a4": (0, 320, 240, 8192, 1000, 4), "a8": (0, 320, 240, 8192, 1000, 8), "a2": (0, 320, 240, 8192, 1000, 2),
     "v2_16k": (0, 320, 240, 16128, 1000, 4), "v3_8k": (1, 640, 480, 8192, 1250, 4), "v3_32k": (1, 640, 480, 32768, 1250, 8),
-    "a16": (0, 320, 240, 8192, 1000, 16), "a24_4k": (0, 320, 240, 4096, 1000, 24),
+    "a16": (0, 320, 240, 8192, 1000, 16), "a24_4k": (0, 320, 240, 4096, 1000, 24), "a6": (0, 320, 240, 8192, 1000, 6),
 }
 
 
