@@ -8,7 +8,7 @@ import numpy as np
 import oracle_lib as O
 from psxavenc_amd import adpcm
 
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = total_units = 0
 t0 = time.time()

@@ -18,7 +18,7 @@ def budget_limit(codec, w, h):
     return int(geo.max_frame_size_limit)
 
 
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)      # second argument: another seed, other frames and budgets
 total = bad = 0
 t0 = time.time()
 for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
