@@ -1345,13 +1345,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
 
         const int scale = L.scalars[S_RESULT];
         if (tid == 0) {
-            // The hint the next launch's groups start from is the answer of a frame that was predicted right (first guess), or
-            // that agrees with the frame this group did before it.  Not simply "the last frame finished": the frames that
-            // finish last are the ones that needed a second pass, i.e. the minority answer -- it would poison the start of
-            // every following launch (measured: 48 % of the frames restarted at the quarter mark instead of 16 %).
-            const int before = L.scalars[S_HINT];
-            if (scale < 64 && (L.scalars[S_PILOT_GUESS] == scale || (before == scale && L.scalars[S_HINT_BUDGET] == max_size)))
-                job.ticket[2] = (unsigned)scale | ((unsigned)max_size << 8);
+            // The hint the next launch's groups start from is the answer of this launch's LAST frame (by index, not by time of
+            // finishing): the neighbour of the next batch's first frame when batches follow each other, and an unbiased draw
+            // from the batch's answers otherwise.  Not "the last frame finished": the frames that finish last are the ones
+            // that needed a second pass, i.e. the minority answer -- it would poison the start of every following launch
+            // (measured: 48 % of the frames restarted at the quarter mark instead of 16 %).
+            if (scale < 64 && f == job.n_frames - 1) job.ticket[2] = (unsigned)scale | ((unsigned)max_size << 8);
             L.scalars[S_HINT] = scale < 64 ? scale : 0;
             L.scalars[S_HINT_BUDGET] = max_size;
         }
