@@ -546,6 +546,32 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             __syncthreads();
         }
     };
+    // Bit offsets of the macroblocks: exclusive scan in encode order (one wavefront)
+    auto scan_offsets = [&](int lane) {
+        // ... and, for images of several tiles, the first macroblock that STARTS in each tile (streams are in encode
+        // order, a macroblock's stream is shorter than a tile): tile t is then fed by macroblocks
+        // [tile_first[t] - 1, tile_first[t + 1]) -- the one before may straddle into it
+        if (lane <= kMaxTiles) L.scalars[S_TILE_FIRST0 + lane] = in_loop(nmb);
+        uint32_t carry = 0;
+        int prev_tile = -1;
+        for (int base = 0; base < nmb; base += 64) {
+            const int mbe = base + lane;
+            const int bits = mbe < nmb ? (int)(L.rec[mbe] >> 16) : 0;
+            const int incl = wave::inclusive_scan_add(bits);
+            const uint32_t D = carry + (uint32_t)(incl - bits);
+            if (mbe < nmb) L.mb_off[mbe] = D;
+            int tile = mbe < nmb ? (int)((2u + (D >> 5)) / (uint32_t)job.out_tile) : 0x7FFF;
+            const int before = __builtin_amdgcn_update_dpp(prev_tile, tile, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
+            if (mbe < nmb && tile != before && tile <= kMaxTiles) L.scalars[S_TILE_FIRST0 + tile] = mbe;
+            prev_tile = __builtin_amdgcn_readlane(tile, 63);
+            carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        }
+    };
+    // small frames: wavefront 1 scans after every emit pass, while thread 0 decides what happens next (the offsets are needed
+    // if this pass's stream turns out to be the answer; otherwise the next emit pass's scan overwrites them) -- one barrier
+    // and one single-wavefront phase fewer per frame.  Large frames (a scan of 19 chunks at 640x480) scan once, when the
+    // answer is known.
+    const bool scan_early = nmb <= 512;
     int n_done = 0;
     if (STATS) t_start = t_mark = wall_clock64();
     unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
@@ -1294,6 +1320,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
             if (!aborted) flush();
             group_sync(3);
+            if (scan_early && wid == 1 && emit_scale && !aborted) scan_offsets(lane);
             if (tid == 0) {
                 MdecSearch st = *srch;
                 if (aborted) {
@@ -1371,30 +1398,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             continue;
         }
 
-        // =====================================================================================
-        // Bit offsets of the macroblocks: exclusive scan in encode order (wave 0)
-        // =====================================================================================
-        if (wid == 0) {
-            // ... and, for images of several tiles, the first macroblock that STARTS in each tile (streams are in encode
-            // order, a macroblock's stream is shorter than a tile): tile t is then fed by macroblocks
-            // [tile_first[t] - 1, tile_first[t + 1]) -- the one before may straddle into it
-            if (lane <= kMaxTiles) L.scalars[S_TILE_FIRST0 + lane] = in_loop(nmb);
-            uint32_t carry = 0;
-            int prev_tile = -1;
-            for (int base = 0; base < nmb; base += 64) {
-                const int mbe = base + lane;
-                const int bits = mbe < nmb ? (int)(L.rec[mbe] >> 16) : 0;
-                const int incl = wave::inclusive_scan_add(bits);
-                const uint32_t D = carry + (uint32_t)(incl - bits);
-                if (mbe < nmb) L.mb_off[mbe] = D;
-                int tile = mbe < nmb ? (int)((2u + (D >> 5)) / (uint32_t)job.out_tile) : 0x7FFF;
-                const int before = __builtin_amdgcn_update_dpp(prev_tile, tile, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
-                if (mbe < nmb && tile != before && tile <= kMaxTiles) L.scalars[S_TILE_FIRST0 + tile] = mbe;
-                prev_tile = __builtin_amdgcn_readlane(tile, 63);
-                carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-            }
+        if (!scan_early) {
+            if (wid == 0) scan_offsets(lane);
+            group_sync(5);
         }
-        group_sync(5);
 
         // =====================================================================================
         // Merge: macroblock streams (dword-aligned in staging) -> their bit positions in the frame image.
@@ -1537,7 +1544,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are
     //      stream-ordered, see psxav_hip.h)
     if (tid == 0) {
-        __threadfence();
         if (atomicAdd(&job.ticket[1], 1u) == gridDim.x - 1u) {
             job.ticket[0] = 0u;
             job.ticket[1] = 0u;
