@@ -218,7 +218,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
     c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
     if (const char* e = getenv("PSXHIP_MDEC_GRID")) { const int g = atoi(e); if (g > 0 && g < c->groups_max) c->groups_max = g; }   // experiments
-    c->prio_pattern = 0x2FE01u;
+    c->prio_pattern = 0x2EE01u;      // younger group raised 6 steps in 8, older 1 (re-swept on mdec-k2.23: tools/gpu_prio_sweep.py)
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
 

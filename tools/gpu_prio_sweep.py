@@ -6,7 +6,7 @@ from psxavenc_amd import synth
 from psxavenc_amd.mdec import MdecEncoder
 CASES = {"a4": (0, 320, 240, 8192, 1000, 4), "a8": (0, 320, 240, 8192, 1000, 8), "a16": (0, 320, 240, 8192, 1000, 16),
          "v2_16k": (0, 320, 240, 16128, 1000, 4), "a2": (0, 320, 240, 8192, 1000, 2)}
-pats = [int(x, 0) for x in sys.argv[1:]] or [0x2FE01]
+pats = [int(x, 0) for x in sys.argv[1:]] or [0x2EE01]
 data = {}
 for name, (codec, w, h, budget, n, amp) in CASES.items():
     d = synth.frames_device(w, h, 1, 0, n, amp, device=0)
