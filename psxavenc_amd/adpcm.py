@@ -250,11 +250,11 @@ def xa_assemble_device(d_units, n_sectors, settings, first_lba=0, d_eof=None):
 def pick_chunking(total_units):
     """(chunk_units, warmup_units) for speculate-and-verify: few verify passes vs enough chunks to fill the GPU
     (same rule as psxhip_audio_api.cpp; tools/gpu_adpcm_sweep.py)."""
-    c = total_units // 16384
+    c = total_units // 8192
     p = 64
-    while p * 2 <= c and p < 1024:
+    while p * 2 <= c and p < 4096:
         p *= 2
-    return p, (32 if p >= 1024 else 16)
+    return p, (128 if p >= 4096 else 32 if p >= 1024 else 16)
 
 
 class AdpcmSession:

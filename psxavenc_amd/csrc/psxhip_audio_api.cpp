@@ -24,14 +24,16 @@ namespace {
 // streams at least this long are also split along time (psxhip_adpcm_encode_chains_chunked)
 constexpr int kChunkedThreshold = 4096;
 
-// chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass), short enough
-// that there are >= ~16 k chunks to fill 256 CUs (tools/gpu_adpcm_sweep.py); warm-up 16 or 32 units
+// chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass, and tonal material
+// does not fall into the same state within a thousand units), short enough that there are >= ~8 k chunks -- 1600+
+// wavefronts -- to fill 256 CUs (tools/gpu_adpcm_sweep.py: 13 M units, tonal: chunks of 1024 are 14 % faster than 512;
+// 78 M units: 4096 is 8 % faster than 1024; noise: within 3 %); warm-up 16 .. 128 units
 inline void pick_chunking(long long total_units, int* chunk_units, int* warmup_units) {
-    long long c = total_units / 16384;
+    long long c = total_units / 8192;
     int p = 64;
-    while (p * 2 <= c && p < 1024) p *= 2;
+    while (p * 2 <= c && p < 4096) p *= 2;
     *chunk_units = p;
-    *warmup_units = p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 64 either
+    *warmup_units = p >= 4096 ? 128 : p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 1024 either
 }
 
 // Device scratch of the host-buffer entry points.  The reference calls psx_audio_spu_encode once per 28 samples and
