@@ -71,7 +71,7 @@ struct FrameJob {
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
     const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
-    unsigned int* ticket;    // [4]: [2] = last answer | budget << 8 of any group (a hint that survives launches),: next frame to hand out, workgroups finished (self-resetting)
+    unsigned int* ticket;    // [4]: [0] next frame to hand out, [1] workgroups finished (both self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches)
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     int ck_margin;               // quarter-pass checkpoint: how far (thousandths of its standard error) a projection has to be on the wrong side
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
@@ -106,7 +106,7 @@ enum {
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
     S_HINT_BUDGET,      // ... and its budget
-    S_SHARED_HINT,      // answer | budget << 8 of the last frame any group finished before this group started
+    S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -846,8 +846,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         //      at a few scales, scaled up to the frame, predict the answer
         // A group that has just encoded a frame with the same budget skips the pilot and starts from that frame's answer
         // (consecutive tickets are neighbouring frames); the quarter-pass checkpoint catches the cases where it is off.
-        // A group's first frame borrows the answer of the last frame ANY group finished before this launch's groups started
-        // (the tail of the previous batch -- temporally adjacent when batches follow each other in a stream).
+        // A group's first frame borrows the answer of the previous launch's last frame (the tail of the previous batch --
+        // temporally adjacent when batches follow each other in a stream).
         int hint = L.scalars[S_HINT];
         int hint_budget = L.scalars[S_HINT_BUDGET];
         if (hint < 1) {
