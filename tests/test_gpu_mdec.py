@@ -433,3 +433,34 @@ def test_host_path_chunks_over_two_streams_and_page_locked_buffers():
     assert np.array_equal(wide[:, :int(budgets.max())], want) and np.array_equal(res2, want_res)
     assert (wide[:, int(budgets.max()):] == 0xEE).all()          # bytes past the row's budget width are the caller's
     enc.close()
+
+
+def test_single_frame_calls_follow_the_content(torch_cuda, monkeypatch):
+    """The drop-in call pattern (one frame per launch, filefmt.c:637-661): the first guess of a call is the answer of the
+    call before it -- also right after the content changed (the hint a launch leaves behind is its last frame's answer,
+    whether or not that frame's own first guess was right).  Read from the diagnostics instantiation's per-frame record;
+    every output byte against the oracle."""
+    import ctypes as C
+    from psxavenc_amd import _lib
+    monkeypatch.setenv("PSXHIP_MDEC_STATS", "1")
+    w, h, budget = 320, 240, 8192
+    calm = O.synth_frames(w, h, 1, seed=5, amp=4)
+    busy = O.synth_frames(w, h, 1, seed=6, amp=16)
+    enc = encoder(0, w, h, budget)
+    NT = 8 + 4 * 1024 + 16 + 2048
+    seen = []
+    for fr in (calm, calm, busy, busy, busy, calm, calm):
+        want, want_res, rc = O.mdec_encode(0, w, h, fr, budget)
+        assert rc == 0
+        out, res = enc.encode_frames_host(fr, budget)
+        assert_same(out[:, :budget], res, want, want_res, "single-frame call")
+        t = (C.c_ulonglong * NT)()
+        _lib.check(_lib.lib().psxhip_mdec_read_stats(enc._h, t, NT, 0))
+        rec = int(t[8 + 4 * 1024 + 16])
+        seen.append((rec & 0xFF, (rec >> 16) & 0xFF, rec >> 24))       # first guess, answer, passes
+    enc.close()
+    calm_scale, busy_scale = seen[1][1], seen[3][1]
+    assert busy_scale > calm_scale + 2, seen
+    for k in (1, 3, 4, 6):                   # the second call on the same content starts from the right scale ...
+        assert seen[k][0] == seen[k][1], seen
+    assert seen[2][0] == calm_scale and seen[5][0] == busy_scale, seen      # ... the first one after a cut from the old one
