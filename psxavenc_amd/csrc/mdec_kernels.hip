@@ -101,8 +101,8 @@ enum {
     S_MB_NEXT,          // pass tickets: next macroblock ticket to hand out
     S_CK_SQ,            // checkpoint: sum over the macroblocks so far of x^2, x = stream bits >> 2 -> spread of the projection
     S_CK_S1,            // ... and of x
-    S_PAD1,             // (keeps S_SEARCH 8-byte aligned)
-    S_ABORT,            // checkpoint verdict: 0 = carry on, else the new guess
+    S_CK_WAVES,         // checkpoint: wavefronts whose sums up to the quarter mark are in
+    S_ABORT,            // checkpoint verdict: new guess | pass number << 8 (a verdict of an earlier pass is stale, not reset)
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
     S_HINT_BUDGET,      // ... and its budget
@@ -1042,10 +1042,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // (every wavefront gets here exactly once, with its first ticket past the quarter mark: the sums then cover
                 //  exactly the first check_t tickets)
                 if (!checked && cur_t >= check_t) {
+                    // No barrier: every wavefront adds its sums when it gets here and carries on; the one that arrives last
+                    // (LDS atomics of a wavefront complete in order, so by then all sums are in) judges the projection.  A
+                    // verdict "stop" empties the ticket counter: every wavefront finishes the (at most two) macroblocks it
+                    // holds tickets for and falls out of the loop by itself -- 8 % of a pass wasted when a pass is stopped,
+                    // two group barriers saved in every pass.
                     checked = true;
                     flush();
-                    group_sync(2);
-                    if (tid == 0) {
+                    int arrived = 0;
+                    if (lane == 0) arrived = atomicAdd(&L.scalars[S_CK_WAVES], 1);
+                    if (__builtin_amdgcn_readfirstlane(arrived) == kWavesPerGroup - 1 && lane == 0) {
                         const int done = L.scalars[S_CK_DONE];
                         long long pa = 0, pb = 0;
                         if (count_scale) pa = (long long)L.scalars[S_CNT_F] * nmb / done + fixed_bits;
@@ -1065,12 +1071,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             margin = (int)(se * (float)job.ck_margin * 0.001f);
                         }
                         const int g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, margin);
-                        L.scalars[S_ABORT] = g;
-                        if (STATS && g && !first_abort) first_abort = g;
-                        if (g) L.scalars[S_ABORTS_LEFT] = L.scalars[S_ABORTS_LEFT] - 1;
+                        if (g) {
+                            L.scalars[S_ABORT] = g | (n_pass << 8);
+                            L.scalars[S_ABORTS_LEFT] = L.scalars[S_ABORTS_LEFT] - 1;
+                            atomicMax(&L.scalars[S_MB_NEXT], 0x40000000);
+                        }
                     }
-                    group_sync(2);
-                    if (L.scalars[S_ABORT]) { aborted = true; break; }
                 }
                 if (WAVES == kWavesSmall) {
                     if ((prio_bits >> (it & 7)) & 1u) __builtin_amdgcn_s_setprio(1);
@@ -1332,20 +1338,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            if (!aborted) flush();
+            flush();
             group_sync(3);
+            const int verdict = L.scalars[S_ABORT];
+            aborted = (verdict >> 8) == n_pass;          // (this pass's verdict; an older one is stale)
+            if (STATS && tid == 0 && aborted && !first_abort) first_abort = verdict & 0xFF;
             if (scan_early && wid == 1 && emit_scale && !aborted) scan_offsets(lane);
             if (tid == 0) {
                 MdecSearch st = *srch;
                 if (aborted) {
                     // the pass was cut short: no evaluation to record, the staging area holds a partial stream
                     st.staged = 0;
-                    const MdecPass np = mdec_search_next(st, L.scalars[S_ABORT], limit_bits, fixed_bits);
+                    const MdecPass np = mdec_search_next(st, verdict & 0xFF, limit_bits, fixed_bits);
                     *srch = st;
                     L.scalars[S_PASS_COUNT] = np.count_scale;
                     L.scalars[S_PASS_EMIT] = np.emit_scale;
                     L.scalars[S_DONE] = np.done;
-                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
                     L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                 } else {
@@ -1366,7 +1375,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_DONE] = np.done;
                 L.scalars[S_RESULT] = st.best;
                 if (!np.done) {
-                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                     if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
                 }
