@@ -222,20 +222,33 @@ def main():
         launch(k)
     torch.cuda.synchronize()
 
-    # one HIP event pair per launch, on the stream the kernel is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * lps)]
+    # HIP events on the stream the kernel is launched on (torch's current stream).  One pair per STEP, bracketing its `lps`
+    # back-to-back launches: the kernel's average launch duration is that time / lps.  (One pair per launch was the first
+    # version: the two extra packets between consecutive kernels cost 5 % of the throughput being measured -- 161 us per
+    # launch against 153 us without them, rocprofv3 putting the kernel itself at 155 us.)  With --streams S > 1 launches
+    # of different streams overlap and a step has no single stream to bracket it: one pair per launch there.
+    per_step = ns == 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * (1 if per_step else lps))]
     _barrier(args, dist, local_rank)
     t0 = time.perf_counter()
-    for k in range(args.steps * lps):
-        ev[k][0].record(streams[k % ns])
-        launch(k)
-        ev[k][1].record(streams[k % ns])
+    for s_ in range(args.steps):
+        if per_step:
+            ev[s_][0].record(streams[0])
+        for j in range(lps):
+            k = s_ * lps + j
+            if not per_step:
+                ev[k][0].record(streams[k % ns])
+            launch(k)
+            if not per_step:
+                ev[k][1].record(streams[k % ns])
+        if per_step:
+            ev[s_][1].record(streams[0])
     _barrier(args, dist, local_rank)
     elapsed_local = time.perf_counter() - t0
 
     per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps)])
     elapsed = max(r[0] for r in per_rank)                   # max over ranks
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [a.elapsed_time(b) / (lps if per_step else 1) for a, b in ev]      # per launch
     kstat = _stats(kernel_ms)
 
     # ---- post-timing: every rank checks its results are sane; rank 0 diffs a sample against the oracle
@@ -304,7 +317,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
-                         "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": alg_bytes, "issue": issue,
+                         "launches_timed": args.steps * lps,
+                         "kernel_ms_method": ("one HIP event pair per step of %d back-to-back launches, / %d; stats over steps" % (lps, lps)) if per_step else "one HIP event pair per launch",
+                         "algorithmic_bytes_per_launch": alg_bytes, "issue": issue,
                          **({"note": "launches of %d contexts overlap: achieved = algorithmic bytes of all launches / elapsed; kernel_ms are "
                                      "per-launch durations while sharing the GPU" % ns} if ns > 1 else {})},
             "cpu_baseline": cpu_baseline,
