@@ -116,43 +116,75 @@ def _profile_traffic(key):
     return None, None, None
 
 
-def _cpu_baseline_mdec(O, codec, w, h, budget, frames, seconds):
-    """oracle/mdec_oracle.c on the host: one core (the reference is single-threaded), then every core with one
-    encoder per thread over disjoint frame ranges (legal: no globals).  ctypes releases the GIL."""
-    import threading
-    n = frames.shape[0]
-    chunk = 125
+def _run_cpu_bench(argv):
+    """oracle/cpu_bench (a C pthread harness over the CPU checker, oracle/cpu_bench.c) -> its JSON line, or None"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "cpu_bench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpu_bench"], check=False, stdout=subprocess.DEVNULL)
+    if not os.path.exists(exe):
+        return None
+    r = subprocess.run([exe] + [str(a) for a in argv], capture_output=True, text=True)
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
 
-    def work(lo, stop_at, counter):
-        done = 0
-        while time.perf_counter() < stop_at:
-            a = (lo + done) % n
-            b = min(n, a + chunk)
-            O.mdec_encode(codec, w, h, frames[a:b], budget)
-            done += b - a
-        counter.append(done)
 
-    t0 = time.perf_counter()
-    c1 = []
-    work(0, t0 + seconds * 0.6, c1)
-    t1 = time.perf_counter() - t0
-    one = c1[0] / t1
+def _cpu_baseline_mdec(codec, w, h, budget, amp, seed, seconds):
+    """oracle/mdec_oracle.c on the host cores of the GPU box: one core (the reference is single-threaded: the faithful
+    number), then every core, one encoder per thread over disjoint frames (legal: no globals).  Timed by a C
+    pthread harness (oracle/cpu_bench.c) on a bounded sample of the same workload (same generator, same budget)."""
     cores = os.cpu_count() or 1
-    nthr = max(1, min(cores, 256))
-    cs, ths = [], []
-    t0 = time.perf_counter()
-    stop = t0 + seconds * 0.4
-    for i in range(nthr):
-        th = threading.Thread(target=work, args=((i * chunk) % n, stop, cs))
-        th.start()
-        ths.append(th)
-    for th in ths:
-        th.join()
-    tn = time.perf_counter() - t0
-    return {"value": round(one, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload in %.1f s (oracle/mdec_oracle.c, gcc -O3; the FFmpeg-linked reference cannot be built here)" % (c1[0], t1),
-            "all_cores": {"value": round(sum(cs) / tn, 2), "unit": "frames/s", "cores": nthr, "nproc": cores,
-                          "sample": "%d frames in %.1f s, one encoder per thread" % (sum(cs), tn)}}
+    one = _run_cpu_bench(["mdec", 1, seconds * 0.6, codec, w, h, budget, amp, seed])
+    if not one:
+        return None
+    out = {"value": one["units_per_sec"], "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same workload in %.1f s (oracle/mdec_oracle.c, gcc -O3, C harness oracle/cpu_bench.c; the "
+                     "FFmpeg-linked reference cannot be built here)" % (one["units"], one["seconds"])}
+    nthr = max(1, min(cores, 1024))
+    many = _run_cpu_bench(["mdec", nthr, seconds * 0.4, codec, w, h, budget, amp, seed])
+    if many:
+        out["all_cores"] = {"value": many["units_per_sec"], "unit": "frames/s", "cores": nthr, "nproc": cores,
+                            "speedup_vs_1_core": round(many["units_per_sec"] / max(one["units_per_sec"], 1e-9), 1),
+                            "per_thread_min": many["per_thread_min"], "per_thread_max": many["per_thread_max"],
+                            "sample": "%d frames in %.1f s, one encoder per pthread" % (many["units"], many["seconds"])}
+    return out
+
+
+def _cpu_baseline_xa(seed, seconds):
+    """the reference's own psx_audio_xa_encode (libpsxav/adpcm.c compiled unchanged into oracle/_ref) when it is there, else
+    this repository's restatement; 37800 Hz 4-bit stereo XACD sectors; one core, then every core (C pthread harness)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "libpsxav_ref.so")
+    extra = [ref] if os.path.exists(ref) else []
+    cores = os.cpu_count() or 1
+    one = _run_cpu_bench(["xa", 1, seconds * 0.6, seed] + extra)
+    if not one:
+        return None
+    out = {"value": one["units_per_sec"], "unit": "sectors/s", "cores": 1, "kind": one["kind"],
+           "sample": "%d sectors of the same signal class in %.1f s (%s; C harness oracle/cpu_bench.c)"
+                     % (one["units"], one["seconds"], "libpsxav/adpcm.c compiled unchanged, gcc -O3 -ffast-math" if one["kind"] == "reference"
+                        else "oracle/adpcm_oracle.c, gcc -O3")}
+    nthr = max(1, min(cores, 1024))
+    many = _run_cpu_bench(["xa", nthr, seconds * 0.4, seed] + extra)
+    if many:
+        out["all_cores"] = {"value": many["units_per_sec"], "unit": "sectors/s", "cores": nthr, "nproc": cores,
+                            "speedup_vs_1_core": round(many["units_per_sec"] / max(one["units_per_sec"], 1e-9), 1),
+                            "sample": "%d sectors in %.1f s, one encoder state per pthread" % (many["units"], many["seconds"])}
+    return out
+
+
+# BASELINE.json's configs by name (SURVEY 8(d)); "sbs_v2" is the headline metric and the default
+PRESETS = {
+    "sbs_v2": dict(workload="sbs", codec=0, width=320, height=240, budget=8192, amp=4, frames=1000, total_frames=0,
+                   baseline_config="sbs v2: 1000 synthetic 320x240 YCbCr frames, 1 GPU, bit-exact check"),
+    "sbs_v3": dict(workload="sbs", codec=1, width=640, height=480, budget=8192, amp=4, frames=0, total_frames=10000,
+                   baseline_config="sbs v3: 10 000 synthetic 640x480 frames sharded across 8xMI355X over xGMI"),
+    "strcd": dict(workload="strcd", frames=1000,
+                  baseline_config="strcd v2: 320x240 15 fps + 37800 Hz 4-bit stereo XA, 2x speed, 1 GPU (combined MDEC+ADPCM path)"),
+    "xacd": dict(workload="xacd", audio_seconds=3600.0, xa_channels=8,
+                 baseline_config="xacd: 8-channel 37800 Hz 4-bit XA, 60 min synthetic audio, 8 GPU ADPCM-only throughput"),
+}
 
 
 def main():
@@ -160,27 +192,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--launches-per-step", type=int, default=16,
-                    help="a step = this many back-to-back launches of the configured batch (so that 20 steps time >= 300 launches)")
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per launch (config 'sbs v2': 1000)")
-    ap.add_argument("--width", type=int, default=320)
-    ap.add_argument("--height", type=int, default=240)
-    ap.add_argument("--budget", type=int, default=8192, help="frame_max_size = sbs alignment (args.c:184)")
-    ap.add_argument("--codec", type=int, default=0, help="0 = BS v2, 1 = v3, 2 = v3dc")
-    ap.add_argument("--amp", type=int, default=4, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="one of BASELINE.json's configs by name: sbs_v2 (the headline metric; the default workload), sbs_v3 (config 4: "
+                         "10 000 640x480 v3 frames STRONG-sharded over the GPUs, 1250 per GPU at 8), strcd (config 3), xacd (config 5: "
+                         "8 channels x 60 min).  Explicit flags below override a preset's values")
+    ap.add_argument("--launches-per-step", type=int, default=0,
+                    help="a step = this many back-to-back launches, cycling over --batches distinct batches (default: enough for "
+                         "--steps steps to time well over a second of GPU work: 400 launches of 1000 320x240 frames)")
+    ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
+    ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--budget", type=int, default=None, help="frame_max_size = sbs alignment (args.c:184)")
+    ap.add_argument("--codec", type=int, default=None, help="0 = BS v2, 1 = v3, 2 = v3dc")
+    ap.add_argument("--amp", type=int, default=None, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="sbs: contexts / streams the launches are dealt over (default 1: in-order launches on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="sbs: skip the untimed secondary measurements (noise +-8, cold context)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
-    ap.add_argument("--workload", choices=["sbs", "xacd", "strcd"], default="sbs",
+    ap.add_argument("--workload", choices=["sbs", "xacd", "strcd"], default=None,
                     help="sbs = the headline MDEC metric (default); xacd = config 5, ADPCM-only XA sectors/s; "
                          "strcd = config 3, MDEC + XA ADPCM muxed into 2352-byte sectors")
-    ap.add_argument("--audio-seconds", type=float, default=600.0, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
-    ap.add_argument("--xa-channels", type=int, default=8)
+    ap.add_argument("--audio-seconds", type=float, default=None, help="xacd: seconds of 37800 Hz stereo audio per XA channel")
+    ap.add_argument("--xa-channels", type=int, default=None)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing: several ranks may share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo)")
     args = ap.parse_args()
+    preset = dict(PRESETS[args.config or "sbs_v2"])
+    if args.workload and args.workload != preset["workload"]:          # --workload alone keeps its round-2 meaning
+        preset = {"workload": args.workload, "baseline_config": None}
+        if args.workload == "sbs":
+            preset = dict(PRESETS["sbs_v2"])
+    defaults = dict(codec=0, width=320, height=240, budget=8192, amp=4, frames=1000, total_frames=0, audio_seconds=600.0, xa_channels=8)
+    for k, v in defaults.items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, preset.get(k, v))
+    args.workload = preset["workload"]
+    args.baseline_config = preset.get("baseline_config")
+    args.config = args.config or ("sbs_v2" if args.workload == "sbs" else args.workload)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _spawn_ranks(args)
     if args.workload == "xacd":
@@ -194,20 +246,31 @@ def main():
     rank, world, local_rank, dev, dist, xdev = _init_dist(args)
 
     from psxavenc_amd import _lib, synth
-    from psxavenc_amd.mdec import MdecEncoder
+    from psxavenc_amd.mdec import MdecEncoder, query_geometry
     from psxavenc_amd.parallel import shard_range
 
-    w, h, budget, n, lps = args.width, args.height, args.budget, args.frames, max(1, args.launches_per_step)
-    first, count = shard_range(n * world, rank, world)     # contiguous frame ranges per rank
-    assert count == n
+    w, h, budget = args.width, args.height, args.budget
+    strong = args.total_frames > 0
+    if strong:          # the job's frames are fixed; every rank takes its contiguous share
+        first, n = shard_range(args.total_frames, rank, world)
+    else:               # every rank encodes its own `--frames` frames per launch
+        first, n = shard_range(args.frames * world, rank, world)
+        assert n == args.frames
+    fsz = w * h * 3 // 2
+    nb = max(1, args.batches)
+    lps = args.launches_per_step
+    if lps <= 0:        # >= ~60 ms of GPU work per step at the measured rates, so that 20 steps time > 1 s
+        lps = max(nb, min(400, int(round(400 * (1000 * 115200) / float(max(n, 1) * fsz)))))
     ns = max(1, args.streams)
     encs = [MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank) for _ in range(ns)]
     enc = encs[0]
-    d_frames = synth.frames_device(w, h, args.seed, first, n, args.amp, device=local_rank)
+    geo = query_geometry(args.codec, w, h, budget, device=local_rank)
+    # `nb` distinct batches of this rank's frames: batch b = the same frame indices drawn with seed + b
+    d_batches = [synth.frames_device(w, h, args.seed + b, first, n, args.amp, device=local_rank) for b in range(nb)]
+    d_frames = d_batches[0]
     ostride = (budget + 3) & ~3
-    d_outs = [torch.zeros((n, ostride), dtype=torch.uint8, device=dev) for _ in range(ns)]
-    d_ress = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(ns)]
-    d_out, d_res = d_outs[0], d_ress[0]
+    d_outs = [torch.zeros((n, ostride), dtype=torch.uint8, device=dev) for _ in range(max(ns, nb))]
+    d_ress = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(max(ns, nb))]
     # --streams 1 (default): every launch on torch's current stream, one context.  --streams S: S contexts on S streams,
     # launches dealt round-robin -- consecutive launches then overlap (one launch's tail with the next one's head), the way
     # two independent encoders sharing a GPU would
@@ -216,7 +279,9 @@ def main():
 
     def launch(k=0):
         i = k % ns
-        encs[i].encode_frames_device(d_frames, budget, d_out=d_outs[i], d_results=d_ress[i], stream=streams[i])
+        b = k % nb
+        o = b if ns == 1 else i          # one output buffer per batch (in-order launches) or per stream (overlapping launches)
+        encs[i].encode_frames_device(d_batches[b], budget, d_out=d_outs[o], d_results=d_ress[o], stream=streams[i])
 
     for k in range(args.warmup * lps):
         launch(k)
@@ -246,27 +311,40 @@ def main():
     _barrier(args, dist, local_rank)
     elapsed_local = time.perf_counter() - t0
 
-    per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps)])
-    elapsed = max(r[0] for r in per_rank)                   # max over ranks
     kernel_ms = [a.elapsed_time(b) / (lps if per_step else 1) for a, b in ev]      # per launch
     kstat = _stats(kernel_ms)
+    alg_bytes = (fsz + budget) * n                       # per launch: NV21 read + frame_max_size written, per frame
+    achieved_local = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
+    if ns > 1:      # launches overlap: a launch's own duration says little, the aggregate rate is what the GPU sustains
+        achieved_local = alg_bytes * args.steps * lps / elapsed_local / 1e9
+    per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps), kstat["mean"], achieved_local])
+    elapsed = max(r[0] for r in per_rank)                   # max over ranks
 
-    # ---- post-timing: every rank checks its results are sane; rank 0 diffs a sample against the oracle
-    res = d_res.cpu().numpy()
-    ok_local = bool(((res[:, 0] >= 1) & (res[:, 0] <= 63)).all())
-    scale_sum = _gather_ranks(dist, xdev, [float(res[:, 0].sum()), float(ok_local)])
+    # ---- post-timing: every rank checks its results are sane; rank 0 diffs a sample of every batch against the oracle
+    ress = [d_ress[b if ns == 1 else 0].cpu().numpy() for b in range(nb if ns == 1 else 1)]
+    res = ress[0]
+    ok_local = all(bool(((r[:, 0] >= 1) & (r[:, 0] <= 63)).all()) for r in ress)
+    scale_sum = _gather_ranks(dist, xdev, [float(sum(int(r[:, 0].sum()) for r in ress)), float(ok_local)])
     parity = None
     cpu_baseline = None
+    secondary = None
     if rank == 0:
         import oracle_lib as O
-        k = min(args.check_frames, n)
-        idx = np.linspace(0, n - 1, k).astype(np.int64)
-        fr = d_frames[torch.from_numpy(idx).to(dev)].cpu().numpy()
-        want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
-        got = d_out[torch.from_numpy(idx).to(dev)].cpu().numpy()[:, :budget]
-        parity = {"frames_checked": int(k), "bit_exact": bool(rc == 0 and np.array_equal(got, want) and np.array_equal(res[idx], want_res))}
+        per = max(1, min(args.check_frames, n * len(ress)) // len(ress))
+        ok, checked = True, 0
+        for b, r in enumerate(ress):
+            idx = np.linspace(0, n - 1, min(per, n)).astype(np.int64)
+            tidx = torch.from_numpy(idx).to(dev)
+            fr = d_batches[b][tidx].cpu().numpy()
+            want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
+            got = d_outs[b if ns == 1 else 0][tidx].cpu().numpy()[:, :budget]
+            ok = ok and bool(rc == 0 and np.array_equal(got, want) and np.array_equal(r[idx], want_res))
+            checked += int(idx.size)
+        parity = {"frames_checked": checked, "batches_checked": len(ress), "bit_exact": ok}
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = _cpu_baseline_mdec(O, args.codec, w, h, budget, d_frames.cpu().numpy(), args.cpu_seconds)
+            cpu_baseline = _cpu_baseline_mdec(args.codec, w, h, budget, args.amp, args.seed, args.cpu_seconds)
+        if world == 1 and not args.no_secondary and ns == 1:
+            secondary = _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first)
 
     version = _lib.lib().psxhip_version().decode()
     wl_key = "sbs codec=%d %dx%d budget=%d frames=%d amp=%d | %s" % (args.codec, w, h, budget, n, args.amp, version)
@@ -276,43 +354,49 @@ def main():
     issue = None
     if pmc and pmc.get("valu_insts_per_launch") and not getattr(args, "share_gpu", False):      # (ranks sharing one GPU: a rank's kernel time is not the GPU's)
         simds, clock_ghz = 256 * 4, 2.4
-        eff_ms = kstat["mean"] if max(1, args.streams) == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock
+        eff_ms = kstat["mean"] if ns == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock
         slots = simds * clock_ghz * 1e9 / 4.0 * (eff_ms * 1e-3)
         issue = {"valu_insts_per_launch": pmc["valu_insts_per_launch"], "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
                  "lds_insts_per_launch": pmc.get("lds_insts_per_launch"),
                  "valu_issue_slots_per_launch": int(slots), "valu_busy_frac": round(pmc["valu_insts_per_launch"] / slots, 4),
                  "note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x this run's mean kernel time; counters from " + str(traffic_src)}
 
-    total_frames = n * world * args.steps * lps
+    total_frames = sum(r[1] for r in per_rank)
     value = total_frames / elapsed
-    alg_bytes = (w * h * 3 // 2 + budget) * n            # per launch: NV21 read + frame_max_size written, per frame
-    achieved = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
-    if ns > 1:      # launches overlap: a launch's own duration says little, the aggregate rate is what the GPU sustains
-        achieved = alg_bytes * args.steps * lps / elapsed_local / 1e9
-    scales, counts = np.unique(res[:, 0], return_counts=True)
+    achieved = achieved_local
+    scales, counts = np.unique(np.concatenate([r[:, 0] for r in ress]), return_counts=True)
 
     if rank == 0:
+        headline = args.codec == 0 and w == 320 and h == 240
         line = {
-            "metric": "bs_v2_320x240_frames_per_sec" if (args.codec == 0 and w == 320 and h == 240) else "bs_frames_per_sec",
+            "metric": "bs_v2_320x240_frames_per_sec" if headline else "bs_%s_%dx%d_frames_per_sec" % (["v2", "v3", "v3dc"][args.codec], w, h),
             "value": round(value, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "timed_region_s": round(elapsed, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "sbs %s: %d synthetic %dx%d NV21 frames per GPU per launch, %d launches per step, frame_max_size %d, "
-                                   "noise +-%d; inputs resident in HBM, outputs stay in HBM (no D2H inside the timed region)"
-                                   % (["v2", "v3", "v3dc"][args.codec], n, w, h, lps, budget, args.amp),
-                       "frames_per_gpu_per_launch": n, "launches_per_step": lps, "width": w, "height": h, "frame_max_size": budget,
+            "config": {"workload": "sbs %s: %s synthetic %dx%d NV21 frames per launch (%d per GPU), %d launches per step cycling over %d distinct "
+                                   "batches, frame_max_size %d, noise +-%d; inputs resident in HBM, outputs stay in HBM (no D2H inside the "
+                                   "timed region)"
+                                   % (["v2", "v3", "v3dc"][args.codec], ("%d" % args.total_frames) if strong else ("%d x %d" % (world, n)), w, h, n,
+                                      lps, nb, budget, args.amp),
+                       "preset": args.config, "baseline_config": args.baseline_config,
+                       "frames_per_gpu_per_launch": n, "launches_per_step": lps, "distinct_batches": nb, "width": w, "height": h,
+                       "frame_max_size": budget,
                        "parallelism": "frames sharded x%d (contiguous ranges per rank), no data-path collective" % world,
+                       "kernel_shape": {"groups_per_cu": geo.groups_per_cu, "wavefronts_per_group": geo.wavefronts_per_group,
+                                        "image_tile_bytes": geo.image_tile_bytes, "frames_in_flight": geo.frames_in_flight},
                        "quant_scale_hist": {str(int(s)): int(c) for s, c in zip(scales, counts)},
                        "library": version, "streams": ns},
-            "per_rank": [{"rank": i, "frames_per_sec": round(r[1] / r[0], 1), "elapsed_s": round(r[0], 4),
+            "per_rank": [{"rank": i, "frames_per_sec": round(r[1] / r[0], 1), "elapsed_s": round(r[0], 4), "kernel_ms": round(r[2], 5),
+                          "roofline_achieved_gbs": round(r[3], 2), "roofline_frac": round(r[3] / HBM_PEAK_GBS, 6),
                           "quant_scale_sum": int(q[0]), "results_sane": bool(q[1])} for i, (r, q) in enumerate(zip(per_rank, scale_sum))],
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -323,6 +407,7 @@ def main():
                          **({"note": "launches of %d contexts overlap: achieved = algorithmic bytes of all launches / elapsed; kernel_ms are "
                                      "per-launch durations while sharing the GPU" % ns} if ns > 1 else {})},
             "cpu_baseline": cpu_baseline,
+            "secondary": secondary,
             "parity": parity,
             "results_sane": all(bool(q[1]) for q in scale_sum),
         }
@@ -331,6 +416,49 @@ def main():
         e.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
+    """Untimed extras of the default line (after the timed region, rank 0, one GPU): the same batch size on content whose
+    answer flips between neighbouring scales (noise +-8), and on a COLD context (no hint from a previous launch: every
+    group's first frame runs the pilot).  The headline is the warm steady state; these are what it does not show."""
+    from psxavenc_amd import synth
+    from psxavenc_amd.mdec import MdecEncoder
+    out = {}
+    d_out = torch.zeros((n, (budget + 3) & ~3), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+
+    def timed(enc, batches, launches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for k in range(launches):
+            enc.encode_frames_device(batches[k % len(batches)], budget, d_out=d_out, d_results=d_res)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / launches
+
+    try:
+        enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+        b8 = [synth.frames_device(w, h, args.seed + 100 + b, first, n, 8, device=local_rank) for b in range(4)]
+        timed(enc, b8, 8)
+        ms = timed(enc, b8, 64)
+        sc, cn = d_res[:, 0].cpu().unique(return_counts=True)
+        out["noise_amp_8"] = {"frames_per_sec": round(n / ms * 1e3, 1), "kernel_ms": round(ms, 5), "launches": 64,
+                              "quant_scale_hist_last_launch": {str(int(s)): int(c) for s, c in zip(sc.tolist(), cn.tolist())}}
+        enc.close()
+        b4 = [synth.frames_device(w, h, args.seed + 200 + b, first, n, args.amp, device=local_rank) for b in range(2)]
+        cold = []
+        for t in range(5):
+            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)      # a fresh context has no hint
+            torch.cuda.synchronize()
+            cold.append(timed(enc, [b4[t % 2]], 1))
+            enc.close()
+        cold.sort()
+        out["cold_context_first_launch"] = {"frames_per_sec": round(n / cold[len(cold) // 2] * 1e3, 1), "kernel_ms_median": round(cold[len(cold) // 2], 5),
+                                            "kernel_ms_min": round(cold[0], 5), "kernel_ms_max": round(cold[-1], 5), "contexts": len(cold)}
+    except Exception as e:          # secondary figures never fail the bench line
+        out["error"] = repr(e)
+    return out
 
 
 def bench_xacd(args):
@@ -405,37 +533,7 @@ def bench_xacd(args):
         got = outs[0][:k].cpu().numpy().reshape(-1)
         parity = {"sectors_checked": int(k), "bit_exact": bool(np.array_equal(got, want))}
         if world == 1 and not args.no_cpu_baseline:
-            # the reference's own psx_audio_xa_encode (libpsxav/adpcm.c:293, compiled unchanged into oracle/_ref) when it is
-            # there, else this repository's restatement; one core, then one encoder per thread over the 16 chains' worth of work
-            import threading
-            use_ref = O.ref() is not None
-            enc = (lambda: O.ref_xa_encode(os_, x, k * sps, lba=0)) if use_ref else (lambda: O.xa_encode(os_, x, k * sps, lba=0))
-            c0 = time.perf_counter()
-            done = 0
-            while time.perf_counter() - c0 < args.cpu_seconds * 0.6:
-                enc()
-                done += k
-            one = done / (time.perf_counter() - c0)
-            nthr = max(1, min(os.cpu_count() or 1, 256))
-            counts = []
-
-            def work(stop_at):
-                d = 0
-                while time.perf_counter() < stop_at:
-                    enc()
-                    d += k
-                counts.append(d)
-            c1 = time.perf_counter()
-            ths = [threading.Thread(target=work, args=(c1 + args.cpu_seconds * 0.4,)) for _ in range(nthr)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-            tn = time.perf_counter() - c1
-            cpu_baseline = {"value": round(one, 2), "unit": "sectors/s", "cores": 1, "kind": "reference" if use_ref else "port",
-                            "sample": "%d sectors of channel 0 (%s)" % (done, "libpsxav/adpcm.c compiled unchanged, gcc -O3 -ffast-math" if use_ref else "oracle/adpcm_oracle.c, gcc -O3"),
-                            "all_cores": {"value": round(sum(counts) / tn, 2), "unit": "sectors/s", "cores": nthr, "nproc": os.cpu_count(),
-                                          "sample": "%d sectors in %.1f s, one encoder state per thread" % (sum(counts), tn)}}
+            cpu_baseline = _cpu_baseline_xa(args.seed, args.cpu_seconds)
         total_sectors = n_sectors * n_ch * args.steps
         value = total_sectors / elapsed
         alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
@@ -445,6 +543,7 @@ def bench_xacd(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "xacd: %d XA channels x stereo x %.0f s @ 37800 Hz, 4-bit, %d sectors per channel, time-sharded x%d"
                                    % (n_ch, n_sectors * sps / 37800.0, n_sectors, world),
+                       "preset": args.config, "baseline_config": args.baseline_config,
                        "verify_passes_last_step": passes, "chunk_units": chunk_units, "warmup_units": warmup_units, "realtime_factor": round(value * sps / 37800.0 / n_ch, 1)},
             "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
@@ -470,11 +569,12 @@ def bench_strcd(args):
     s = strmux.settings(fmt=strmux.FORMAT_STRCD, codec=0, width=w, height=h, fps_num=15, fps_den=1, cd_speed=2)
     first, count = shard_range(n * world, rank, world)
     frames = synth.frames_device(w, h, args.seed, first, n, args.amp, device=local_rank).cpu().numpy()
-    p = strmux.plan(s, n)
-    na = p.n_audio_sectors * p.audio_samples_per_sector
-    pcm = np.zeros((na + 4032) * 2, np.int16)
+    # a little more audio than video, so that the video ends the stream (the reference's loop stops with whichever ends first)
+    na = (strmux.plan(s, n).n_audio_sectors + 2) * 2016 + 100
+    pcm = np.zeros(na * 2, np.int16)
     for c in range(2):
-        pcm[c:2 * na:2] = synth.pcm_device(args.seed, c, 0, na, 0, device=local_rank).cpu().numpy()[:na]
+        pcm[c::2] = synth.pcm_device(args.seed, c, 0, na, 0, device=local_rank).cpu().numpy()[:na]
+    p = strmux.plan(s, n, na)
     sectors = np.zeros((p.n_sectors, p.sector_size), np.uint8)      # the caller's output buffer, reused step after step
     for _ in range(args.warmup):
         strmux.encode(s, frames, pcm, device=local_rank, out=sectors)
@@ -489,21 +589,24 @@ def bench_strcd(args):
     if rank == 0:
         import hashlib
         import oracle_lib as O
-        # parity on a prefix: the oracle loop over the first frames of this rank's stream
-        k = min(20, n)
-        sub, _ = strmux.encode(s, frames[:k], pcm, device=local_rank)
-        osub = _oracle_str_prefix(O, frames[:k], pcm, w, h)
-        parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub[:, :], osub))}
+        # parity on a prefix: the reference's sector loop (tests/str_reference_loop.py over the oracle) on the first frames and
+        # their share of the audio -- a complete little stream with its own tail
+        import str_reference_loop as R
+        k = min(24, n)
+        pk = pcm[:2 * 2016 * 30]
+        sub, _ = strmux.encode(s, frames[:k], pk, device=local_rank)
+        osub, _, _ = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames[:k], pk)
+        parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub, osub))}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             c0 = time.perf_counter()
             done = 0
             while time.perf_counter() - c0 < args.cpu_seconds:
-                done += _oracle_str_prefix(O, frames[:k], pcm, w, h).shape[0]
+                done += R.encode_file_str(7, 0, w, h, 15, 1, 2, frames[:k], pk)[0].shape[0]
             cpu_baseline = {"value": round(done / (time.perf_counter() - c0), 2), "unit": "sectors/s", "cores": 1, "kind": "port",
-                            "sample": "%d sectors (oracle sector loop over the first %d frames, repeated)" % (done, k)}
+                            "sample": "%d sectors (the reference's sector loop restated over the oracle, first %d frames, repeated)" % (done, k)}
         total = p.n_sectors * world * args.steps
-        alg = (w * h * 3 // 2) * n + na * 4 + p.n_sectors * p.sector_size
+        alg = (w * h * 3 // 2) * p2.n_frames_encoded + na * 4 + p.n_sectors * p.sector_size
         print(json.dumps({
             "metric": "strcd_v2_320x240_sectors_per_sec", "value": round(total / elapsed, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -511,50 +614,17 @@ def bench_strcd(args):
             "config": {"workload": "strcd v2: %d frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA per GPU per step -> %d sectors of 2352 bytes "
                                    "(%d video, %d audio); host buffers in and out (PCIe + host interleave inside the timed region)"
                                    % (n, p.n_sectors, p.n_video_sectors, p.n_audio_sectors),
-                       "frames_per_sec": round(n * world * args.steps / elapsed, 1),
-                       "realtime_factor": round(n * world * args.steps / elapsed / 15.0, 1),
-                       "avg_quant_scale": round(p2.quant_scale_sum / n, 3), "stream_sha256": hashlib.sha256(out.tobytes()).hexdigest()},
+                       "preset": args.config, "baseline_config": args.baseline_config, "tail": "reference (filefmt.c:443-450,492-493)",
+                       "frames_encoded_per_step": p2.n_frames_encoded,
+                       "frames_per_sec": round(p2.n_frames_encoded * world * args.steps / elapsed, 1),
+                       "realtime_factor": round(p2.n_frames_encoded * world * args.steps / elapsed / 15.0, 1),
+                       "avg_quant_scale": round(p2.quant_scale_sum / max(1, p2.n_frames_encoded), 3), "stream_sha256": hashlib.sha256(out.tobytes()).hexdigest()},
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": "whole step incl. PCIe and the host interleave, not a single kernel"},
             "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-
-
-def _oracle_str_prefix(O, frames, pcm, w, h):
-    """the reference's STRCD sector loop (filefmt.c:450-503) over the oracle, for bench parity / cpu_baseline"""
-    import ctypes as C
-    import numpy as np
-    oxs = O.XaSettings(1, 1, 37800, 4, 1, 0)
-    interleave, sps, vspb = 8, 2016, 7
-    base, den = 75 * 2 * vspb, interleave * 15
-    ofo = np.zeros(2016 * -(-base // den), np.uint8)
-    ost = O.StrState(0, 0, 0, base, 0, den, 0, 0, ofo.ctypes.data)
-    ast = O.State()
-    out, audio_at = [], []
-    fc, ac, sc = 0, 0, 0
-    n = frames.shape[0]
-    while not (fc >= n and ost.frame_data_offset >= ost.frame_max_size):
-        want = np.zeros(2352, np.uint8)
-        if sc % interleave > 0:
-            O.lib().orc_cdrom_init_sector(O.ptr(want, O.u8p), sc, 1)
-            want[16:20] = [1, 0, 0x08 | 0x40, 0]
-            want[20:24] = want[16:20]
-            fc += O.lib().orc_mdec_encode_sector_str(C.byref(ost), 0, w, h, O.FMT_STRCD, 0x8001, O.ptr(frames[min(fc, n - 1)], O.u8p), O.ptr(want, O.u8p))
-            O.lib().orc_cdrom_calculate_checksums(O.ptr(want, O.u8p), 1)
-        else:
-            w_, ast = O.xa_encode(oxs, pcm[2 * ac:], sps, lba=sc, state=ast)
-            want[:] = w_[:2352]
-            ac += sps
-            audio_at.append(len(out))
-        out.append(want)
-        sc += 1
-    st = np.stack(out)
-    if audio_at:
-        st[audio_at[-1], 0x12] |= 0x80
-        st[audio_at[-1], 0x16] |= 0x80
-    return st
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ typedef struct {
 	int32_t wavefronts_per_group;
 	int32_t frames_in_flight;       /* persistent grid size = compute units * groups_per_cu */
 	int32_t max_frame_size_limit;
-	int32_t reserved;
+	int32_t image_tile_bytes;       /* bytes of the frame image assembled in LDS at a time: the whole budget, or 8 / 4 / 2 KiB */
 	int64_t lds_bytes_per_group;
 	int64_t lds_bytes_per_cu;
 } psxhip_mdec_geometry_t;
@@ -226,13 +226,82 @@ void psxhip_release_scratch(void);
 int psxhip_host_register(void *p, size_t bytes);
 int psxhip_host_unregister(void *p);
 
+/* ---------------------------------------------------------------- several devices behind one call ---- */
+
+/* The reference's host side is one C loop (psxavenc/filefmt.c:633-662 over frames, :450-503 over sectors): a C caller has
+ * no ranks to shard over, so these entry points take a device LIST and shard inside the call -- one host thread, one
+ * encoder context and one pair of pinned staging buffers per list entry.  Frames (mdec.c:678-686: every attempt resets all
+ * bit / DC state) and XA streams (adpcm.c:202-209: a state per channel) are independent units, so the bytes are those of
+ * the single-device call whatever the schedule.  A device may be listed more than once.  The host-buffer path is bound by
+ * the PCIe link of each device (about 440 k 320x240 frames/s), which is what several devices multiply. */
+
+/* contiguous block partition of n_units over `world` workers: the first n_units % world workers get one unit more
+ * (the same partition psxavenc_amd/parallel.py:shard_range uses across ranks) */
+void psxhip_shard_range(int64_t n_units, int rank, int world, int64_t *first, int64_t *count);
+
+/* host-side ticket queue: [0, n_units) handed out in ranges of ticket_units, in order, each exactly once, to any number
+ * of threads (one atomic counter in host memory; no device collective).  _next returns 0 when the queue is empty. */
+typedef struct psxhip_ticket_queue psxhip_ticket_queue_t;
+psxhip_ticket_queue_t *psxhip_ticket_queue_create(int64_t n_units, int64_t ticket_units);
+int psxhip_ticket_queue_next(psxhip_ticket_queue_t *q, int64_t *first, int64_t *count);
+void psxhip_ticket_queue_destroy(psxhip_ticket_queue_t *q);
+
+enum {
+	PSXHIP_SCHED_STATIC = 0,    /* worker d takes psxhip_shard_range(n, d, n_devices) */
+	PSXHIP_SCHED_TICKETS = 1    /* workers draw ranges of ticket_frames frames from a ticket queue until it is empty: a device
+	                               that drew expensive frames (content at a scale boundary costs up to 1.5x) draws fewer */
+};
+
+/* what each worker did (optional out-parameter, one entry per listed device, at most PSXHIP_MULTI_MAX_REPORT) */
+#define PSXHIP_MULTI_MAX_REPORT 64
+typedef struct {
+	int32_t device;
+	int64_t units;       /* frames / streams this worker encoded */
+	int32_t tickets;     /* ranges it drew */
+	double seconds;      /* wall time from the start of the call to this worker's end */
+} psxhip_multi_report_t;
+
+typedef struct psxhip_mdec_multi psxhip_mdec_multi_t;
+int psxhip_mdec_multi_create(psxhip_mdec_multi_t **m, const int *devices, int n_devices, int codec, int width, int height,
+                             int max_frame_size);
+void psxhip_mdec_multi_destroy(psxhip_mdec_multi_t *m);
+int psxhip_mdec_multi_device_count(const psxhip_mdec_multi_t *m);
+/* psxhip_mdec_encode_frames_host over all listed devices; same arguments, same bytes, same results, same return value.
+ * ticket_frames <= 0: a default (1536 frames, halved until every device gets about 8 tickets). */
+int psxhip_mdec_multi_encode_frames_host(psxhip_mdec_multi_t *m, const uint8_t *frames, int n_frames,
+                                         const int32_t *frame_max_sizes, int uniform_max_size, uint8_t *out,
+                                         size_t out_stride, psxhip_mdec_result_t *results, int schedule, int ticket_frames,
+                                         psxhip_multi_report_t *report);
+
+/* psxhip_xa_encode_streams_host with the streams sharded over the listed devices (contiguous stream ranges, e.g. the 8
+ * XA channels of config `xacd` on 8 GPUs); same bytes and states. */
+int psxhip_xa_encode_streams_host_multi(const int *devices, int n_devices, int format, int stereo, int frequency, int bits,
+                                        int file_number, int channel_number, const int16_t *samples, int n_streams,
+                                        int64_t stream_stride, int samples_per_stream, const int32_t *lbas,
+                                        psxhip_adpcm_state_t *states, uint8_t *out, int64_t out_stride, int finalize,
+                                        psxhip_multi_report_t *report);
+
 /* ---------------------------------------------------------------- STR / STRCD / STRV muxer -- */
 
 /* The reference's encode_file_str (psxavenc/filefmt.c:391-520) for inputs that are all there up front: every frame goes
- * through ONE batched MDEC launch (the per-frame budgets are a closed-form function of the frame index,
- * mdec.c:768-775), the audio is one XA stream encoded concurrently by the ADPCM kernels, and the host interleaves
- * 2016-byte slices of the finished frames with the finished audio sectors on the reference's sector schedule
+ * through ONE batched MDEC call (the per-frame budgets are a closed-form function of the frame index, mdec.c:768-775),
+ * sharded over the handle's devices; the audio is one XA stream encoded concurrently by the ADPCM kernels, and the host
+ * interleaves 2016-byte slices of the finished frames with the finished audio sectors on the reference's sector schedule
  * ((sector % interleave) > 0 = video, filefmt.c:454-461).  Fields mirror args_t (psxavenc/args.h). */
+enum {
+	/* How the stream ends.  REFERENCE (default, 0) = the CLI's sector loop fed by its decoder (decoding.c:510-560) when the
+	 * whole input is there: end_of_input is raised as soon as no more than `frames_needed` (>= 2, filefmt.c:443-446) frames or
+	 * no more than one sector's worth of audio are left; the loop then runs until the frame in progress is written out
+	 * (filefmt.c:450) -- the last frames_needed frames of the input are NOT encoded (the FIXME at filefmt.c:442), a stream
+	 * whose audio is shorter than its video ends with the audio -- every audio sector from that point on carries EOF
+	 * (:492-493), and an audio slot with no samples left is an all-zero sector that also widens the video share of the
+	 * trailing-audio schedule (:483-484).
+	 * COMPLETE = every frame is encoded, the stream ends with the last frame's last sector, short audio is padded with
+	 * silence and only the last audio sector carries EOF (what a caller who wants all of its frames in the file asks for). */
+	PSXHIP_STR_TAIL_REFERENCE = 0,
+	PSXHIP_STR_TAIL_COMPLETE = 1
+};
+
 typedef struct {
 	int32_t format;             /* format_t: 6 = STR (2336-byte sectors), 7 = STRCD (2352), 9 = STRV */
 	int32_t video_codec;        /* bs_codec_t */
@@ -245,32 +314,52 @@ typedef struct {
 	int32_t audio_frequency;    /* 18900 / 37800 */
 	int32_t audio_bit_depth;    /* 4 / 8 */
 	int32_t audio_xa_file, audio_xa_channel;
+	int32_t tail_mode;          /* PSXHIP_STR_TAIL_* */
+	int32_t reserved;
 } psxhip_str_settings_t;
 
 typedef struct {
-	int32_t n_sectors;          /* the stream ends with the last frame's last sector */
-	int32_t n_video_sectors, n_audio_sectors;
+	int32_t n_sectors;
+	int32_t n_video_sectors, n_audio_sectors;   /* audio slots, incl. those with no samples left */
 	int32_t sector_size;        /* 2336 or 2352 */
 	int32_t interleave;         /* sectors per block: 1 audio + (interleave - 1) video */
 	int32_t audio_samples_per_sector;   /* per channel */
 	int32_t max_frame_size;     /* largest per-frame budget */
-	int32_t reserved;
+	int32_t n_frames_encoded;   /* frames that are part of the stream (REFERENCE tail: n_frames - frames_needed, or fewer when
+	                               the audio ends first) */
 	int64_t quant_scale_sum;    /* filled by psxhip_str_encode_host (mdec_encoder_state_t.quant_scale_sum) */
 } psxhip_str_plan_t;
 
-/* sector counts and sizes for n_frames frames (what a caller needs to size the output) */
-int psxhip_str_plan(const psxhip_str_settings_t *settings, int n_frames, psxhip_str_plan_t *plan);
+/* sector counts and sizes for n_frames frames and pcm_samples_per_channel samples of audio (what a caller needs to size the
+ * output; the amount of audio matters because the reference's stream ends with whichever input ends first) */
+int psxhip_str_plan(const psxhip_str_settings_t *settings, int n_frames, int64_t pcm_samples_per_channel,
+                    psxhip_str_plan_t *plan);
+/* what each sector of the stream holds, in stream order: returns the sector count (= plan.n_sectors) and fills
+ * min(cap, count) entries */
+enum { PSXHIP_STR_SECTOR_VIDEO = 0, PSXHIP_STR_SECTOR_AUDIO = 1, PSXHIP_STR_SECTOR_EMPTY = 2 /* audio slot, no samples left */ };
+typedef struct {
+	int32_t kind;
+	int32_t frame;      /* video: 0-based frame; else -1 */
+	int32_t index;      /* video: chunk index inside the frame (mdec.c:794); audio: index of the XA sector; empty: -1 */
+	int32_t eof;        /* audio: the sector carries the EOF submode bit */
+} psxhip_str_sector_t;
+int psxhip_str_plan_sectors(const psxhip_str_settings_t *settings, int n_frames, int64_t pcm_samples_per_channel,
+                            psxhip_str_sector_t *sectors, int cap);
 /* frame_max_size of frames first_frame .. first_frame + n_frames - 1 (so that any rank can budget its own frame range) */
 int psxhip_str_frame_budgets(const psxhip_str_settings_t *settings, int first_frame, int n_frames, int32_t *budgets);
+
+/* A muxer handle owns what is kept between calls: the encoder contexts (device buffers, pinned staging) of the listed
+ * devices and the page-locked buffer the bitstreams land in.  Handles are independent (no process-global state); calls
+ * on ONE handle are serialised. */
+typedef struct psxhip_str_ctx psxhip_str_ctx_t;
+int psxhip_str_create(psxhip_str_ctx_t **ctx, const int *devices, int n_devices);
+void psxhip_str_destroy(psxhip_str_ctx_t *ctx);
 /* frames: n_frames NV21 frames back to back (w*h*3/2 bytes each); pcm: int16, interleaved L,R when stereo,
- * pcm_samples_per_channel of them (shorter than the video: padded with silence).  out: plan.n_sectors * sector_size
- * bytes.  Sector bytes the reference leaves unwritten (it muxes into an uninitialised stack buffer) are zero; the EOF
- * submode bit is set on the last audio sector. */
-int psxhip_str_encode_host(int device, const psxhip_str_settings_t *settings, const uint8_t *frames, int n_frames,
+ * pcm_samples_per_channel of them.  out: plan.n_sectors * sector_size bytes.  Sector bytes the reference leaves unwritten
+ * (it muxes into an uninitialised stack buffer) are zero. */
+int psxhip_str_encode_host(psxhip_str_ctx_t *ctx, const psxhip_str_settings_t *settings, const uint8_t *frames, int n_frames,
                            const int16_t *pcm, int64_t pcm_samples_per_channel, uint8_t *out, size_t out_size,
                            psxhip_str_plan_t *plan);
-/* psxhip_str_encode_host keeps its MDEC context (device + pinned staging buffers) between calls; this releases it */
-void psxhip_str_release(void);
 
 /* ---------------------------------------------------------------- SPU / VAG / SPUI / VAGI files ---- */
 

@@ -170,6 +170,7 @@ extern "C" int psxhip_mdec_query_geometry(int device, int codec, int width, int 
         out->lds_bytes_per_group = (int64_t)need;
         out->lds_bytes_per_cu = (int64_t)lds_cu;
         out->frames_in_flight = fits ? prop.multiProcessorCount * (large ? 1 : 2) : 0;
+        out->image_tile_bytes = fits ? (ow - 2) * 4 : 0;
         // largest budget that still fits this frame size (the LDS need grows by 8 bytes per budget dword)
         int lo = 8, hi = 1 << 20;
         while (lo < hi) {
@@ -377,6 +378,15 @@ void parallel_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
 extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_t* frames, int n_frames,
                                               const int32_t* frame_max_sizes, int uniform_max_size, uint8_t* out,
                                               size_t out_stride, psxhip_mdec_result_t* results) {
+    return psxhip_mdec_encode_frames_host_rows(c, frames, n_frames, frame_max_sizes, uniform_max_size, out, out_stride, results, 0);
+}
+
+// row_bytes > 0: the bytes written per output row (>= every budget of the batch) -- a caller that splits one batch with
+// per-frame budgets over several calls (psxhip_multi.cpp) passes the whole batch's largest budget, so that every row is
+// written exactly as wide as the unsplit call would have written it
+extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const uint8_t* frames, int n_frames,
+                                                   const int32_t* frame_max_sizes, int uniform_max_size, uint8_t* out,
+                                                   size_t out_stride, psxhip_mdec_result_t* results, int row_bytes) {
     if (!c || !frames || !out || !results || n_frames < 0) {
         psxhip_set_error("encode_frames_host: NULL argument");
         return PSXHIP_EINVAL;
@@ -398,6 +408,13 @@ extern "C" int psxhip_mdec_encode_frames_host(psxhip_mdec_ctx_t* c, const uint8_
     } else if (uniform_max_size < 8 || uniform_max_size > c->max_frame_size) {
         psxhip_set_error("encode_frames_host: frame_max_size %d outside [8, %d]", uniform_max_size, c->max_frame_size);
         return PSXHIP_EINVAL;
+    }
+    if (row_bytes > 0) {
+        if (row_bytes < max_size || row_bytes > c->max_frame_size) {
+            psxhip_set_error("encode_frames_host: row width %d outside [%d, %d]", row_bytes, max_size, c->max_frame_size);
+            return PSXHIP_EINVAL;
+        }
+        max_size = row_bytes;
     }
     if ((size_t)max_size > out_stride) {
         psxhip_set_error("encode_frames_host: out_stride %zu smaller than the largest budget %d", out_stride, max_size);

@@ -159,6 +159,17 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
                                              int channel_number, const int16_t* samples, int n_streams,
                                              int64_t stream_stride, int samples_per_stream, const int32_t* lbas,
                                              psxhip_adpcm_state_t* states, uint8_t* out, int64_t out_stride, int finalize) {
+    return psxhip_xa_encode_streams_host_flags(device, format, stereo, frequency, bits, file_number, channel_number, samples, n_streams,
+                                               stream_stride, samples_per_stream, lbas, states, out, out_stride, finalize, nullptr);
+}
+
+// eof_flags (optional, n_streams x sectors): which sectors get the EOF submode bit -- the reference's encode_file_str
+// finalises EVERY audio sector once its decoder has seen the end of the input (filefmt.c:492-493), not only the last one
+extern "C" int psxhip_xa_encode_streams_host_flags(int device, int format, int stereo, int frequency, int bits, int file_number,
+                                                   int channel_number, const int16_t* samples, int n_streams,
+                                                   int64_t stream_stride, int samples_per_stream, const int32_t* lbas,
+                                                   psxhip_adpcm_state_t* states, uint8_t* out, int64_t out_stride, int finalize,
+                                                   const uint8_t* eof_flags) {
     if (!samples || !states || !out || n_streams < 0 || samples_per_stream < 0 || (bits != 4 && bits != 8) ||
         (format != 0 && format != 1)) {
         psxhip_set_error("xa_encode_streams_host: bad argument");
@@ -198,7 +209,9 @@ extern "C" int psxhip_xa_encode_streams_host(int device, int format, int stereo,
             base[(size_t)i * ch + c] = i * units_per_stream + c;
         }
     std::vector<uint8_t> eof((size_t)n_streams * sectors, 0);
-    if (finalize)
+    if (eof_flags)
+        memcpy(eof.data(), eof_flags, eof.size());
+    else if (finalize)
         for (int i = 0; i < n_streams; i++) eof[(size_t)i * sectors + sectors - 1] = 1;
 
     g_pool_device = device;

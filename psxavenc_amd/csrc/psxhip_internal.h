@@ -45,6 +45,15 @@ int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int 
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
 
+int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t *ctx, const uint8_t *frames, int n_frames,
+                                        const int32_t *frame_max_sizes, int uniform_max_size, uint8_t *out,
+                                        size_t out_stride, psxhip_mdec_result_t *results, int row_bytes);
+/* psxhip_xa_encode_streams_host with one EOF flag per sector (n_streams x sectors, or NULL = `finalize` semantics) */
+int psxhip_xa_encode_streams_host_flags(int device, int format, int stereo, int frequency, int bits, int file_number,
+                                        int channel_number, const int16_t *samples, int n_streams, int64_t stream_stride,
+                                        int samples_per_stream, const int32_t *lbas, psxhip_adpcm_state_t *states,
+                                        uint8_t *out, int64_t out_stride, int finalize, const uint8_t *eof_flags);
+
 void psxhip_set_error(const char *fmt, ...);
 
 #ifdef __cplusplus

@@ -2,14 +2,19 @@
 //
 // What psxavenc's encode_file_str does sector by sector (psxavenc/filefmt.c:391-520 with :73-91, around
 // encode_sector_str, mdec.c:757-836, and psx_audio_xa_encode, adpcm.c:293-332), restated for inputs that are all
-// there up front: the per-frame byte budgets are a closed-form function of the frame index (mdec.c:768-775), so
-// every frame is encoded in ONE batched MDEC launch; the audio is one XA stream encoded by the ADPCM kernels
-// concurrently (its own host thread and stream); the host then interleaves 2016-byte slices of the finished frames
-// with the finished audio sectors following the reference's sector schedule.  No encoding happens on the host.
+// there up front: the sector loop is first run dry (make_plan: which frame slice / audio sector lands where, which
+// frames are part of the stream at all, which audio sectors carry EOF -- incl. the reference's end-of-input model);
+// the per-frame byte budgets are a closed-form function of the frame index (mdec.c:768-775), so every frame is encoded
+// in ONE batched MDEC call sharded over the handle's devices; the audio is one XA stream encoded by the ADPCM kernels
+// concurrently (its own host thread and stream); the host then cuts the finished frames into sectors and interleaves
+// them with the finished audio sectors.  No encoding happens on the host.  No process-global state: everything kept
+// between calls lives in a psxhip_str_ctx_t.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -18,18 +23,20 @@
 #include "../../include/psxav_mdec.h"
 #include "psxhip_internal.h"
 
-namespace {
+struct psxhip_str_ctx {
+    // One multi-device MDEC encoder is kept between calls (creating one allocates pinned staging buffers per device, which
+    // costs more than encoding a thousand frames), re-created when the geometry changes
+    std::vector<int> devices;
+    psxhip_mdec_multi_t* mdec = nullptr;
+    int key[4] = {-1, -1, -1, -1};          // codec, width, height, max_frame_size
+    // ... and so is the buffer the frames' bitstreams land in before they are cut into sectors: page-locked, so the MDEC
+    // host path writes it by DMA
+    uint8_t* bs = nullptr;
+    size_t bs_cap = 0;
+    std::mutex mu;                          // calls on ONE handle are serialised; handles are independent of each other
+};
 
-// One MDEC context is kept between calls (creating one allocates pinned staging buffers, which costs more than
-// encoding a thousand frames); psxhip_str_release() drops it.
-std::mutex g_ctx_mu;
-psxhip_mdec_ctx_t* g_ctx = nullptr;
-int g_ctx_key[5] = {-1, -1, -1, -1, -1};      // device, codec, width, height, max_frame_size
-// ... and so is the buffer the frames' bitstreams land in before they are cut into sectors: page-locked, so the MDEC host
-// path writes it by DMA; calls are serialised on it
-std::mutex g_call_mu;
-uint8_t* g_bs = nullptr;
-size_t g_bs_cap = 0;
+namespace {
 
 void put_le16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 void put_le32(uint8_t* p, unsigned v) { put_le16(p, v & 0xFFFF); put_le16(p + 2, v >> 16); }
@@ -54,177 +61,276 @@ bool settings_ok(const psxhip_str_settings_t* s) {
         return false;
     if (s->str_fps_num <= 0 || s->str_fps_den <= 0 || (s->str_cd_speed != 1 && s->str_cd_speed != 2)) return false;
     if (s->audio_channels < 0 || s->audio_channels > 2) return false;
+    if (s->tail_mode != PSXHIP_STR_TAIL_REFERENCE && s->tail_mode != PSXHIP_STR_TAIL_COMPLETE) return false;
     if (s->audio_channels && ((s->audio_frequency != 18900 && s->audio_frequency != 37800) ||
                               (s->audio_bit_depth != 4 && s->audio_bit_depth != 8)))
         return false;
     return true;
 }
 
-// sector schedule, filefmt.c:454-461
-bool is_video_sector(const psxhip_str_settings_t* s, int interleave, int video_per_block, int sector) {
-    if (!s->audio_channels) return true;
-    if (s->trailing_audio) return (sector % interleave) < video_per_block;
-    return (sector % interleave) > 0;
-}
+struct Sector {
+    int32_t frame;      // >= 0: video sector of that frame; -1: audio sector; -2: audio slot with no samples left
+    int32_t at;         // video: byte offset into the frame's bitstream; audio: index of the XA sector
+    uint8_t eof;        // audio: EOF submode bit (psx_audio_xa_encode_finalize)
+};
 
 struct Plan {
     psxhip_str_plan_t pub;
     int base, den;                // frame_block_base_overflow / frame_block_overflow_den, filefmt.c:431-432
-    int video_per_block;
-    std::vector<int32_t> budgets; // frame_max_size of every frame, mdec.c:768-775
+    std::vector<int32_t> budgets; // frame_max_size of every frame in the stream, mdec.c:768-775
+    std::vector<Sector> sectors;
+    int64_t audio_samples;        // per channel, handed to the XA encoder over the whole stream
 };
 
-int make_plan(const psxhip_str_settings_t* s, int n_frames, Plan* pl) {
-    if (!settings_ok(s) || n_frames < 0) {
+// The sector loop of encode_file_str (filefmt.c:450-503) run dry: which frame slice / audio sector lands in which sector
+// follows from the frame count, the amount of audio and the settings alone.
+//
+// tail_mode PSXHIP_STR_TAIL_REFERENCE models the reference's decoder (decoding.c:510-560) for an input that is all there:
+// ensure_av_data(needed_audio, frames_needed) raises end_of_input as soon as no more than one sector's worth of audio or no
+// more than `frames_needed` frames are left to hand out (its loop polls while count <= needed, and the only way out with
+// nothing left to read is end_of_input = true).  From then on the loop runs until the current frame is written out
+// (filefmt.c:450) -- the last frames_needed frames are never encoded (the FIXME at :442) -- every audio sector is finalised
+// (:492-493), and an audio slot with no samples left stays as the sector buffer was (zero here) and widens the video share of
+// the trailing-audio schedule (:483-484).
+// PSXHIP_STR_TAIL_COMPLETE: every frame is encoded, the stream ends with the last frame's last sector, short audio is padded
+// with silence and only the last audio sector carries EOF.
+int make_plan(const psxhip_str_settings_t* s, int n_frames, int64_t pcm_samples_per_channel, Plan* pl) {
+    if (!settings_ok(s) || n_frames < 0 || pcm_samples_per_channel < 0) {
         psxhip_set_error("psxhip_str: bad settings");
         return PSXHIP_EINVAL;
     }
     memset(&pl->pub, 0, sizeof pl->pub);
+    pl->budgets.clear();
+    pl->sectors.clear();
+    pl->audio_samples = 0;
     const psx_audio_xa_settings_t xa = xa_settings_of(s);
+    const int ch = s->audio_channels;
     int interleave = 1, sps = 0, vpb = 1;
-    if (s->audio_channels) {              // 1/N audio, (N-1)/N video
+    if (ch) {                             // 1/N audio, (N-1)/N video, filefmt.c:399-403
         interleave = (int)psx_audio_xa_get_sector_interleave(xa) * s->str_cd_speed;
         sps = (int)psx_audio_xa_get_samples_per_sector(xa);
         vpb = interleave - 1;
     }
     pl->base = 75 * s->str_cd_speed * vpb * s->str_fps_den;
     pl->den = interleave * s->str_fps_num;
-    pl->video_per_block = vpb;
-    pl->budgets.resize((size_t)n_frames);
-    int num = 0, max_budget = 0;
-    long long video_sectors = 0;
-    for (int i = 0; i < n_frames; i++) {
-        num += pl->base;
-        const int size = num / pl->den * 2016;
-        num %= pl->den;
-        if (size < 2016) {
-            psxhip_set_error("psxhip_str: frame %d would get no sector (frame rate too high for this CD speed)", i);
-            return PSXHIP_EINVAL;
-        }
-        pl->budgets[(size_t)i] = size;
-        if (size > max_budget) max_budget = size;
-        video_sectors += size / 2016;
+    pl->pub.sector_size = (int32_t)psx_audio_xa_get_buffer_size_per_sector(xa);
+    pl->pub.interleave = interleave;
+    pl->pub.audio_samples_per_sector = sps;
+    if (pl->base / pl->den < 1) {
+        psxhip_set_error("psxhip_str: a frame would get no sector (frame rate too high for this CD speed)");
+        return PSXHIP_EINVAL;
     }
-    // the stream ends with the last frame's last sector
-    long long n = 0, v = 0;
-    while (v < video_sectors) {
-        if (is_video_sector(s, interleave, vpb, (int)n)) v++;
-        n++;
+    // filefmt.c:443-446
+    const double frame_size = (double)pl->base / (double)pl->den;
+    int frames_needed = (int)ceil((double)vpb / frame_size);
+    if (frames_needed < 2) frames_needed = 2;
+    const bool reference = s->tail_mode == PSXHIP_STR_TAIL_REFERENCE;
+
+    long long V = n_frames;                                    // frames the decoder still holds
+    long long A = ch ? pcm_samples_per_channel * ch : 0;       // interleaved samples the decoder still holds
+    bool eoi = false;
+    int offset = 0, max_size = 0, num = 0, frame = -1, audio_sectors = 0, video_sectors = 0, max_budget = 0;
+    // complete mode: the audio slots of the whole stream are filled (silence when the PCM runs out)
+    for (long long n = 0;; n++) {
+        if (reference) {
+            if (eoi && offset >= max_size) break;              // loop condition, filefmt.c:450
+            const long long needed_audio = (long long)sps * ch;
+            if ((needed_audio && A <= needed_audio) || V <= frames_needed) eoi = true;     // ensure_av_data, decoding.c:540-553
+        } else if (frame + 1 >= n_frames && offset >= max_size) {
+            break;
+        }
         if (n > 0x7FFFFFF0ll) {
             psxhip_set_error("psxhip_str: stream too long");
             return PSXHIP_EINVAL;
         }
+        bool video;                                            // filefmt.c:454-461
+        if (!sps) video = true;
+        else if (s->trailing_audio) video = (n % interleave) < vpb;
+        else video = (n % interleave) > 0;
+        Sector sec;
+        if (video) {
+            while (offset >= max_size) {                       // encode_sector_str moves on to the next frame, mdec.c:768-780
+                frame++;
+                num += pl->base;
+                max_size = num / pl->den * 2016;
+                num %= pl->den;
+                offset = 0;
+                pl->budgets.push_back(max_size);
+                if (max_size > max_budget) max_budget = max_size;
+                V--;
+            }
+            sec.frame = frame;
+            sec.at = offset;
+            sec.eof = 0;
+            offset += 2016;
+            video_sectors++;
+        } else if (reference) {
+            long long sl = A / ch;                             // filefmt.c:476-484
+            if (sl > sps) sl = sps;
+            if (!sl) vpb++;
+            sec.frame = sl ? -1 : -2;
+            sec.at = sl ? audio_sectors : 0;
+            sec.eof = (eoi && sl) ? 1 : 0;                     // :492-493 (finalize does nothing to a sector of length 0)
+            if (sl) {
+                audio_sectors++;
+                pl->audio_samples += sl;
+                A -= sl * ch;
+            }
+        } else {
+            sec.frame = -1;
+            sec.at = audio_sectors++;
+            sec.eof = 0;
+            pl->audio_samples += sps;
+        }
+        pl->sectors.push_back(sec);
     }
-    pl->pub.n_sectors = (int32_t)n;
-    pl->pub.n_video_sectors = (int32_t)video_sectors;
-    pl->pub.n_audio_sectors = (int32_t)(n - video_sectors);
-    pl->pub.sector_size = (int32_t)psx_audio_xa_get_buffer_size_per_sector(xa);
-    pl->pub.interleave = interleave;
-    pl->pub.audio_samples_per_sector = sps;
+    if (!reference && audio_sectors > 0)                       // only the last audio sector carries EOF
+        for (size_t i = pl->sectors.size(); i-- > 0;)
+            if (pl->sectors[i].frame == -1) { pl->sectors[i].eof = 1; break; }
+    pl->pub.n_sectors = (int32_t)pl->sectors.size();
+    pl->pub.n_video_sectors = video_sectors;
+    pl->pub.n_audio_sectors = (int32_t)pl->sectors.size() - video_sectors;
+    pl->pub.n_frames_encoded = frame + 1;
     pl->pub.max_frame_size = max_budget;
     return PSXHIP_OK;
 }
 
 }  // namespace
 
-extern "C" void psxhip_str_release(void) {
-    std::lock_guard<std::mutex> call(g_call_mu);
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    psxhip_mdec_destroy(g_ctx);
-    g_ctx = nullptr;
-    g_ctx_key[0] = -1;
-    if (g_bs) (void)hipHostFree(g_bs);
-    g_bs = nullptr;
-    g_bs_cap = 0;
+extern "C" int psxhip_str_create(psxhip_str_ctx_t** out, const int* devices, int n_devices) {
+    if (!out) return PSXHIP_EINVAL;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) {
+        psxhip_set_error("psxhip_str_create: need 1..64 devices");
+        return PSXHIP_EINVAL;
+    }
+    const int have = psxhip_device_count();
+    if (have <= 0) {
+        psxhip_set_error("no HIP device visible (libpsxav_hip has no CPU fallback)");
+        return PSXHIP_EDEVICE;
+    }
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= have) {
+            psxhip_set_error("psxhip_str_create: device %d out of range (%d visible)", devices[i], have);
+            return PSXHIP_EINVAL;
+        }
+    psxhip_str_ctx* c = new (std::nothrow) psxhip_str_ctx;
+    if (!c) return PSXHIP_ENOMEM;
+    c->devices.assign(devices, devices + n_devices);
+    *out = c;
+    return PSXHIP_OK;
 }
 
-extern "C" int psxhip_str_plan(const psxhip_str_settings_t* settings, int n_frames, psxhip_str_plan_t* plan) {
+extern "C" void psxhip_str_destroy(psxhip_str_ctx_t* c) {
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        psxhip_mdec_multi_destroy(c->mdec);
+        c->mdec = nullptr;
+        if (c->bs) {
+            (void)hipSetDevice(c->devices[0]);
+            (void)hipHostFree(c->bs);
+        }
+        c->bs = nullptr;
+    }
+    delete c;
+}
+
+extern "C" int psxhip_str_plan(const psxhip_str_settings_t* settings, int n_frames, int64_t pcm_samples_per_channel,
+                               psxhip_str_plan_t* plan) {
     Plan pl;
-    const int rc = make_plan(settings, n_frames, &pl);
+    const int rc = make_plan(settings, n_frames, pcm_samples_per_channel, &pl);
     if (plan) *plan = pl.pub;
     return rc;
 }
 
+extern "C" int psxhip_str_plan_sectors(const psxhip_str_settings_t* settings, int n_frames, int64_t pcm_samples_per_channel,
+                                       psxhip_str_sector_t* sectors, int cap) {
+    Plan pl;
+    const int rc = make_plan(settings, n_frames, pcm_samples_per_channel, &pl);
+    if (rc) return rc;
+    const int n = (int)pl.sectors.size();
+    for (int i = 0; i < n && i < cap && sectors; i++) {
+        const Sector& sc = pl.sectors[(size_t)i];
+        sectors[i].kind = sc.frame >= 0 ? PSXHIP_STR_SECTOR_VIDEO : (sc.frame == -1 ? PSXHIP_STR_SECTOR_AUDIO : PSXHIP_STR_SECTOR_EMPTY);
+        sectors[i].frame = sc.frame >= 0 ? sc.frame : -1;
+        sectors[i].index = sc.frame >= 0 ? sc.at / 2016 : (sc.frame == -1 ? sc.at : -1);
+        sectors[i].eof = sc.eof;
+    }
+    return n;
+}
+
 extern "C" int psxhip_str_frame_budgets(const psxhip_str_settings_t* settings, int first_frame, int n_frames, int32_t* budgets) {
     if (!budgets || first_frame < 0 || n_frames < 0) return PSXHIP_EINVAL;
+    // the budget sequence does not depend on how the stream ends: plan all frames in the complete mode (mdec.c:768-775)
+    psxhip_str_settings_t s2;
+    if (!settings) return PSXHIP_EINVAL;
+    s2 = *settings;
+    s2.tail_mode = PSXHIP_STR_TAIL_COMPLETE;
     Plan pl;
-    const int rc = make_plan(settings, first_frame + n_frames, &pl);
+    const int rc = make_plan(&s2, first_frame + n_frames, 0, &pl);
     if (rc) return rc;
     for (int i = 0; i < n_frames; i++) budgets[i] = pl.budgets[(size_t)(first_frame + i)];
     return PSXHIP_OK;
 }
 
-extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s, const uint8_t* frames, int n_frames,
+extern "C" int psxhip_str_encode_host(psxhip_str_ctx_t* c, const psxhip_str_settings_t* s, const uint8_t* frames, int n_frames,
                                       const int16_t* pcm, int64_t pcm_samples_per_channel, uint8_t* out, size_t out_size,
                                       psxhip_str_plan_t* plan_out) {
+    if (!c) {
+        psxhip_set_error("psxhip_str_encode_host: NULL handle");
+        return PSXHIP_EINVAL;
+    }
     Plan pl;
-    int rc = make_plan(s, n_frames, &pl);
+    int rc = make_plan(s, n_frames, pcm_samples_per_channel, &pl);
     if (plan_out) *plan_out = pl.pub;
     if (rc) return rc;
-    if (n_frames == 0) return PSXHIP_OK;
-    if (!frames || !out || (s->audio_channels && !pcm && pcm_samples_per_channel > 0) || pcm_samples_per_channel < 0) {
+    const int ns = pl.pub.n_sectors;
+    if (ns == 0) return PSXHIP_OK;
+    const int nf = pl.pub.n_frames_encoded;
+    if ((nf && !frames) || !out || (s->audio_channels && !pcm && pcm_samples_per_channel > 0)) {
         psxhip_set_error("psxhip_str_encode_host: NULL argument");
         return PSXHIP_EINVAL;
     }
     const size_t ssz = (size_t)pl.pub.sector_size;
-    if (out_size < ssz * (size_t)pl.pub.n_sectors) {
-        psxhip_set_error("psxhip_str_encode_host: output needs %zu bytes, %zu given", ssz * (size_t)pl.pub.n_sectors, out_size);
+    if (out_size < ssz * (size_t)ns) {
+        psxhip_set_error("psxhip_str_encode_host: output needs %zu bytes, %zu given", ssz * (size_t)ns, out_size);
         return PSXHIP_EINVAL;
     }
 
-    // ---- video: every frame in one batched call (its own streams inside the context)
-    std::lock_guard<std::mutex> call(g_call_mu);
+    // ---- video: every frame of the stream in one batched call, sharded over the handle's devices
+    std::lock_guard<std::mutex> call(c->mu);
+    const int device = c->devices[0];
     const size_t ostride = (size_t)pl.pub.max_frame_size;
-    if ((size_t)n_frames * ostride > g_bs_cap) {
+    if ((size_t)nf * ostride > c->bs_cap) {
         if (hipSetDevice(device) != hipSuccess) { psxhip_set_error("psxhip_str_encode_host: no such device %d", device); return PSXHIP_EDEVICE; }
-        if (g_bs) (void)hipHostFree(g_bs);
-        g_bs = nullptr;
-        g_bs_cap = 0;
-        if (hipHostMalloc((void**)&g_bs, (size_t)n_frames * ostride, hipHostMallocDefault) != hipSuccess) {
+        if (c->bs) (void)hipHostFree(c->bs);
+        c->bs = nullptr;
+        c->bs_cap = 0;
+        // page-locked for every device of the list (the default flags of a multi-GPU process map it for all of them)
+        if (hipHostMalloc((void**)&c->bs, (size_t)nf * ostride, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
-            psxhip_set_error("psxhip_str_encode_host: out of pinned host memory (%zu bytes)", (size_t)n_frames * ostride);
+            psxhip_set_error("psxhip_str_encode_host: out of pinned host memory (%zu bytes)", (size_t)nf * ostride);
             return PSXHIP_ENOMEM;
         }
-        g_bs_cap = (size_t)n_frames * ostride;
+        c->bs_cap = (size_t)nf * ostride;
     }
-    uint8_t* const bs = g_bs;
-    std::vector<psxhip_mdec_result_t> res((size_t)n_frames);
+    uint8_t* const bs = c->bs;
+    std::vector<psxhip_mdec_result_t> res((size_t)(nf ? nf : 1));
     int rc_video = PSXHIP_OK;
     char err_video[256] = "";
     std::vector<uint8_t> xa_out;
-    // ---- interleave (filefmt.c:450-503): which frame slice / audio sector lands in which sector is known from the plan alone
     const int at = s->format == FORMAT_STR ? 0x08 : (s->format == FORMAT_STRCD ? 0x18 : 0x00);     // mdec.c:822-829
-    // which frame slice / audio sector lands in which sector: a short serial walk; the sectors themselves (2 KiB of copying
-    // and a 2 KiB EDC each) are then built by a few threads, each on its own range
-    const int ns = pl.pub.n_sectors;
-    std::vector<int32_t> sec_frame((size_t)ns), sec_off((size_t)ns);        // video: frame, byte offset; audio: -1, audio sector
-    int frames_in_stream = 0;
-    {
-        int frame = -1, offset = 0, budget = 0, audio_sector = 0;
-        for (int n = 0; n < ns; n++) {
-            if (is_video_sector(s, pl.pub.interleave, pl.video_per_block, n)) {
-                if (offset >= budget) {                    // encode_sector_str moves on to the next frame, mdec.c:766-779
-                    frame++;
-                    budget = pl.budgets[(size_t)frame];
-                    offset = 0;
-                }
-                sec_frame[(size_t)n] = frame;
-                sec_off[(size_t)n] = offset;
-                offset += 2016;
-            } else {
-                sec_frame[(size_t)n] = -1;
-                sec_off[(size_t)n] = audio_sector++;
-            }
-        }
-        frames_in_stream = frame + 1;
-    }
+    // Which frame slice / audio sector lands in which sector is in the plan; the sectors themselves (2 KiB of copying and a
+    // 2 KiB EDC each) are built by a few threads, each on its own range.
     // `video`: build the video sectors of [n0, n1), else its audio sectors -- the two kinds are built by different threads at
     // different times (whichever of the frame encode and the XA encode finishes first has its sectors cut while the other runs)
     auto build = [&](int n0, int n1, bool video) {
         uint8_t sector[PSX_CDROM_SECTOR_SIZE];
         for (int n = n0; n < n1; n++) {
             uint8_t* dst = out + (size_t)n * ssz;
-            const int frame = sec_frame[(size_t)n], offset = sec_off[(size_t)n];
+            const Sector& sc = pl.sectors[(size_t)n];
+            const int frame = sc.frame, offset = sc.at;
             if ((frame >= 0) != video) continue;
             if (frame >= 0) {
                 const int budget = pl.budgets[(size_t)frame];
@@ -260,6 +366,10 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
                 memcpy(hd + 0x20, fo + offset, 2016);
                 psx_cdrom_calculate_checksums((psx_cdrom_sector_t*)sector, PSX_CDROM_SECTOR_TYPE_MODE2_FORM1);
                 memcpy(dst, sector, ssz);
+            } else if (frame == -2) {
+                // no samples left: psx_audio_xa_encode writes nothing (adpcm.c:310) and the reference puts out whatever its
+                // stack buffer held; zero here
+                memset(dst, 0, ssz);
             } else {
                 memcpy(dst, xa_out.data() + (size_t)offset * ssz, ssz);
                 if (s->format == FORMAT_STRCD) {
@@ -285,27 +395,33 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
     };
 
     std::thread video([&]() {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        const int key[5] = {device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size};
-        if (!g_ctx || memcmp(key, g_ctx_key, sizeof key) != 0) {
-            psxhip_mdec_destroy(g_ctx);
-            g_ctx = nullptr;
-            rc_video = psxhip_mdec_create(&g_ctx, device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size);
-            if (rc_video == PSXHIP_OK) memcpy(g_ctx_key, key, sizeof key);
+        if (nf == 0) return;
+        const int key[4] = {s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size};
+        if (!c->mdec || memcmp(key, c->key, sizeof key) != 0) {
+            psxhip_mdec_multi_destroy(c->mdec);
+            c->mdec = nullptr;
+            rc_video = psxhip_mdec_multi_create(&c->mdec, c->devices.data(), (int)c->devices.size(), s->video_codec, s->video_width,
+                                                s->video_height, pl.pub.max_frame_size);
+            if (rc_video == PSXHIP_OK) memcpy(c->key, key, sizeof key);
         }
         if (rc_video == PSXHIP_OK)
-            rc_video = psxhip_mdec_encode_frames_host(g_ctx, frames, n_frames, pl.budgets.data(), 0, bs, ostride, res.data());
+            rc_video = psxhip_mdec_multi_encode_frames_host(c->mdec, frames, nf, pl.budgets.data(), 0, bs, ostride, res.data(),
+                                                            PSXHIP_SCHED_STATIC, 0, nullptr);
         if (rc_video) snprintf(err_video, sizeof err_video, "%s", psxhip_last_error());     // thread-local text
         else build_all(true);
     });
 
-    // ---- audio: one XA stream, concurrently
-    const int na = pl.pub.n_audio_sectors, sps = pl.pub.audio_samples_per_sector, ch = s->audio_channels;
+    // ---- audio: one XA stream, concurrently (on the list's first device: 3 ms of work next to the frames')
+    const int ch = s->audio_channels;
+    int na = 0;
+    for (const Sector& sc : pl.sectors) na += sc.frame == -1;
     int rc_audio = PSXHIP_OK;
     if (na > 0) {
-        // the reference relies on zero padding after the end of the PCM data (decoding.c:497-503); a stream whose audio
-        // is shorter than its video gets silence here (the reference writes an uninitialised sector, filefmt.c:476-490)
-        const int64_t need = (int64_t)na * sps;
+        // The XA encoder is handed pl.audio_samples per channel (the sum of the sector loop's samples_length, filefmt.c:476-479).
+        // A short last sector is completed from zeros: what lies past the end of the PCM data is zero in the reference's
+        // decoder buffer too (decoding.c:395-398,521-527), which is what its stereo tail over-reads.  The complete
+        // mode fills every audio slot, with silence once the PCM has run out.
+        const int64_t need = pl.audio_samples;
         std::vector<int16_t> padded;
         const int16_t* src = pcm;
         if (pcm_samples_per_channel < need) {
@@ -313,16 +429,19 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
             if (pcm_samples_per_channel) memcpy(padded.data(), pcm, (size_t)pcm_samples_per_channel * ch * sizeof(int16_t));
             src = padded.data();
         }
+        std::vector<uint8_t> eof((size_t)na, 0);
+        for (const Sector& sc : pl.sectors)
+            if (sc.frame == -1) eof[(size_t)sc.at] = sc.eof;
         xa_out.resize((size_t)na * ssz);
         psxhip_adpcm_state_t st[2] = {{0, 0}, {0, 0}};
         const int32_t lba0 = 0;
         const int fmt = s->format == FORMAT_STRCD ? 1 : 0;
-        rc_audio = psxhip_xa_encode_streams_host(device, fmt, ch == 2, s->audio_frequency, s->audio_bit_depth,
-                                                 s->audio_xa_file, s->audio_xa_channel, src, 1, need * ch, (int)need, &lba0, st,
-                                                 xa_out.data(), (int64_t)xa_out.size(), 1);
-        if (rc_audio > 0) rc_audio = PSXHIP_OK;
+        rc_audio = psxhip_xa_encode_streams_host_flags(device, fmt, ch == 2, s->audio_frequency, s->audio_bit_depth,
+                                                       s->audio_xa_file, s->audio_xa_channel, src, 1, need * ch, (int)need,
+                                                       &lba0, st, xa_out.data(), (int64_t)xa_out.size(), 0, eof.data());
+        if (rc_audio > 0) rc_audio = rc_audio == (int)(na * ssz) ? PSXHIP_OK : PSXHIP_EINVAL;
     }
-    if (rc_audio == PSXHIP_OK && na > 0) build_all(false);
+    if (rc_audio == PSXHIP_OK) build_all(false);
     video.join();
     if (rc_video) {
         psxhip_set_error("psxhip_str_encode_host: video: %s", err_video);
@@ -331,7 +450,7 @@ extern "C" int psxhip_str_encode_host(int device, const psxhip_str_settings_t* s
     if (rc_audio) return rc_audio;
 
     long long qsum = 0;
-    for (int f = 0; f < frames_in_stream; f++) qsum += res[(size_t)f].quant_scale;
+    for (int f = 0; f < nf; f++) qsum += res[(size_t)f].quant_scale;
     pl.pub.quant_scale_sum = qsum;
     if (plan_out) *plan_out = pl.pub;
     return PSXHIP_OK;

@@ -122,3 +122,19 @@ def unregister_host(a):
     L = _lib.lib()
     L.psxhip_host_unregister.argtypes = [C.c_void_p]
     _lib.check(L.psxhip_host_unregister(a.ctypes.data))
+
+
+class MdecGeometry(C.Structure):
+    """psxhip_mdec_geometry_t"""
+    _fields_ = [("fits", C.c_int32), ("groups_per_cu", C.c_int32), ("wavefronts_per_group", C.c_int32),
+                ("frames_in_flight", C.c_int32), ("max_frame_size_limit", C.c_int32), ("image_tile_bytes", C.c_int32),
+                ("lds_bytes_per_group", C.c_int64), ("lds_bytes_per_cu", C.c_int64)]
+
+
+def query_geometry(video_codec, video_width, video_height, max_frame_size, device=0):
+    """psxhip_mdec_query_geometry: fit / shape / image tile of a geometry before creating a context for it"""
+    L = _lib.lib()
+    L.psxhip_mdec_query_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MdecGeometry)]
+    g = MdecGeometry()
+    _lib.check(L.psxhip_mdec_query_geometry(device, video_codec, video_width, video_height, max_frame_size, C.byref(g)))
+    return g

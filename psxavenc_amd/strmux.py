@@ -9,6 +9,8 @@ import numpy as np
 from . import _lib
 
 FORMAT_STR, FORMAT_STRCD, FORMAT_STRV = 6, 7, 9
+TAIL_REFERENCE, TAIL_COMPLETE = 0, 1      # PSXHIP_STR_TAIL_*: how the stream ends (see include/psxav_hip.h)
+PLENTY_OF_AUDIO = 1 << 40                 # plan(): "the audio never ends before the video does"
 
 
 class StrSettings(C.Structure):
@@ -16,35 +18,60 @@ class StrSettings(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "format", "video_codec", "video_width", "video_height", "str_fps_num", "str_fps_den", "str_cd_speed",
         "str_video_id", "trailing_audio", "audio_channels", "audio_frequency", "audio_bit_depth", "audio_xa_file",
-        "audio_xa_channel")]
+        "audio_xa_channel", "tail_mode", "reserved")]
 
 
 class StrPlan(C.Structure):
     _fields_ = [("n_sectors", C.c_int32), ("n_video_sectors", C.c_int32), ("n_audio_sectors", C.c_int32),
                 ("sector_size", C.c_int32), ("interleave", C.c_int32), ("audio_samples_per_sector", C.c_int32),
-                ("max_frame_size", C.c_int32), ("reserved", C.c_int32), ("quant_scale_sum", C.c_int64)]
+                ("max_frame_size", C.c_int32), ("n_frames_encoded", C.c_int32), ("quant_scale_sum", C.c_int64)]
 
 
 def settings(fmt=FORMAT_STRCD, codec=0, width=320, height=240, fps_num=15, fps_den=1, cd_speed=2, video_id=0x8001,
-             trailing_audio=False, channels=2, frequency=37800, bits=4, xa_file=1, xa_channel=0):
-    """defaults = config 'strcd v2' (args.c:149-187 + SURVEY 3.2)"""
+             trailing_audio=False, channels=2, frequency=37800, bits=4, xa_file=1, xa_channel=0, tail=TAIL_REFERENCE):
+    """defaults = config 'strcd v2' (args.c:149-187 + SURVEY 3.2); tail = the reference's end-of-input model"""
     return StrSettings(fmt, codec, width, height, fps_num, fps_den, cd_speed, video_id, int(trailing_audio), channels,
-                       frequency, bits, xa_file, xa_channel)
+                       frequency, bits, xa_file, xa_channel, tail, 0)
 
 
 def _bind():
     L = _lib.lib()
-    L.psxhip_str_plan.argtypes = [C.POINTER(StrSettings), C.c_int, C.POINTER(StrPlan)]
+    L.psxhip_str_plan.argtypes = [C.POINTER(StrSettings), C.c_int, C.c_int64, C.POINTER(StrPlan)]
     L.psxhip_str_frame_budgets.argtypes = [C.POINTER(StrSettings), C.c_int, C.c_int, C.c_void_p]
-    L.psxhip_str_encode_host.argtypes = [C.c_int, C.POINTER(StrSettings), C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+    L.psxhip_str_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+    L.psxhip_str_destroy.argtypes = [C.c_void_p]
+    L.psxhip_str_destroy.restype = None
+    L.psxhip_str_encode_host.argtypes = [C.c_void_p, C.POINTER(StrSettings), C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_size_t, C.POINTER(StrPlan)]
     return L
 
 
-def plan(s, n_frames):
+def plan(s, n_frames, pcm_samples_per_channel=PLENTY_OF_AUDIO):
     p = StrPlan()
-    _lib.check(_bind().psxhip_str_plan(C.byref(s), n_frames, C.byref(p)))
+    _lib.check(_bind().psxhip_str_plan(C.byref(s), n_frames, pcm_samples_per_channel, C.byref(p)))
     return p
+
+
+class StrSector(C.Structure):
+    """psxhip_str_sector_t"""
+    _fields_ = [("kind", C.c_int32), ("frame", C.c_int32), ("index", C.c_int32), ("eof", C.c_int32)]
+
+
+SECTOR_VIDEO, SECTOR_AUDIO, SECTOR_EMPTY = 0, 1, 2
+
+
+def plan_sectors(s, n_frames, pcm_samples_per_channel=PLENTY_OF_AUDIO):
+    """what each sector of the stream holds: (n_sectors, 4) int32 [kind, frame, index, eof]"""
+    L = _bind()
+    L.psxhip_str_plan_sectors.argtypes = [C.POINTER(StrSettings), C.c_int, C.c_int64, C.c_void_p, C.c_int]
+    n = L.psxhip_str_plan_sectors(C.byref(s), n_frames, pcm_samples_per_channel, None, 0)
+    if n < 0:
+        _lib.check(n)
+    out = np.zeros((n, 4), np.int32)
+    if n:
+        n2 = L.psxhip_str_plan_sectors(C.byref(s), n_frames, pcm_samples_per_channel, out.ctypes.data, n)
+        assert n2 == n
+    return out
 
 
 def frame_budgets(s, first_frame, n_frames):
@@ -53,21 +80,58 @@ def frame_budgets(s, first_frame, n_frames):
     return out
 
 
-def encode(s, frames, pcm=None, device=0, out=None):
-    """frames: (n, w*h*3/2) uint8; pcm: int16, interleaved when stereo.  Returns (sectors (n_sectors, sector_size) uint8, plan).
-    `out`: optional preallocated (n_sectors, sector_size) uint8 array to write into (a caller muxing stream after stream
-    reuses its buffer instead of faulting in 23 MB of fresh pages per call)."""
-    frames = np.ascontiguousarray(frames, dtype=np.uint8)
-    n = frames.shape[0]
-    p = plan(s, n)
-    if out is None:
-        out = np.zeros((p.n_sectors, p.sector_size), np.uint8)
-    assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (p.n_sectors, p.sector_size)
-    if pcm is None:
-        pcm = np.zeros(0, np.int16)
-    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
-    per_ch = pcm.size // max(1, s.audio_channels)
-    rc = _bind().psxhip_str_encode_host(device, C.byref(s), frames.ctypes.data, n, pcm.ctypes.data if pcm.size else None,
-                                        per_ch, out.ctypes.data, out.size, C.byref(p))
-    _lib.check(rc)
-    return out, p
+class StrMuxer:
+    """psxhip_str_ctx_t: owns what is kept between calls (encoder contexts of the listed devices, pinned buffers)."""
+
+    def __init__(self, devices=(0,)):
+        self.devices = tuple(int(d) for d in devices)
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        _lib.check(_bind().psxhip_str_create(C.byref(self._h), arr, len(self.devices)))
+
+    def close(self):
+        if self._h:
+            _bind().psxhip_str_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, s, frames, pcm=None, out=None):
+        """frames: (n, w*h*3/2) uint8; pcm: int16, interleaved when stereo.  Returns (sectors (n_sectors, sector_size) uint8, plan).
+        `out`: optional preallocated (n_sectors, sector_size) uint8 array to write into (a caller muxing stream after stream
+        reuses its buffer instead of faulting in 23 MB of fresh pages per call)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        if pcm is None:
+            pcm = np.zeros(0, np.int16)
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        per_ch = pcm.size // max(1, s.audio_channels)
+        p = plan(s, n, per_ch)
+        if out is None:
+            out = np.zeros((p.n_sectors, p.sector_size), np.uint8)
+        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (p.n_sectors, p.sector_size)
+        rc = _bind().psxhip_str_encode_host(self._h, C.byref(s), frames.ctypes.data, n, pcm.ctypes.data if pcm.size else None,
+                                            per_ch, out.ctypes.data, out.size, C.byref(p))
+        _lib.check(rc)
+        return out, p
+
+
+_muxers = {}
+
+
+def encode(s, frames, pcm=None, device=0, out=None, devices=None):
+    """convenience for tests / bench: one cached StrMuxer per device list"""
+    key = tuple(devices) if devices is not None else (int(device),)
+    if key not in _muxers:
+        _muxers[key] = StrMuxer(key)
+    return _muxers[key].encode(s, frames, pcm, out=out)
+
+
+def release():
+    for m in _muxers.values():
+        m.close()
+    _muxers.clear()

@@ -424,3 +424,86 @@ def test_extreme_signals_where_most_candidates_saturate():
             want, _ = O.xa_encode(so, padded, n, lba=3)
             got = adpcm.xa_encode_streams(s, padded[None, :], n, lbas=np.array([3], np.int32))[0]
             assert got.size == want.size and np.array_equal(got, want), ("xa", bits, k)
+
+
+# ---------------------------------------------------------------- several devices behind one call
+def test_xa_streams_over_a_device_list_equal_single_device():
+    """psxhip_xa_encode_streams_host_multi over {0, 0, 0}: the 8 XA channels of config 'xacd' (reduced length) sharded
+    3 / 3 / 2 over three host threads -- bytes and carried states of the single-device call"""
+    from psxavenc_amd import adpcm, multi
+    s = adpcm.XaSettings(1, True, 37800, 4, 1, 0)
+    n = 2016 * 40 + 700
+    pcm = np.stack([stereo_pad(c % 3, n, 90 + c, pad=0) for c in range(8)])
+    lbas = np.arange(8, dtype=np.int32) * 1000
+    st1 = np.zeros((8, 2, 2), np.int32)
+    want = adpcm.xa_encode_streams(s, pcm, n, lbas=lbas, states=st1, finalize=True)
+    got, st2, rep = multi.xa_encode_streams_multi((0, 0, 0), s, pcm, lbas=lbas, finalize=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(st2.reshape(8, 2, 2), st1)
+    assert [r["units"] for r in rep] == [3, 3, 2]
+    one, _, _ = multi.xa_encode_streams_multi((0, 0, 0), s, pcm[:1], lbas=lbas[:1], finalize=True)      # fewer streams than devices
+    assert np.array_equal(one[0], want[0])
+
+
+def test_xacd_config5_full_size_every_sector_against_the_reference():
+    """BASELINE config 5 at its full size: 8 XA channels x stereo x 37800 Hz x 60 min = 540 000 sectors (77.76 M sound
+    units) in one speculate-and-verify session on one GPU.  EVERY sector of every channel is compared with the reference's
+    own psx_audio_xa_encode (oracle/_ref, libpsxav/adpcm.c compiled unchanged; the restatement when that is absent) run
+    serially on the host, one channel per thread; plus the size-independent properties: time codes, subheaders, EDC."""
+    import threading
+    import torch
+    from psxavenc_amd import adpcm, synth
+    from psxavenc_amd.parallel import run_time_sharded
+    settings = adpcm.XaSettings(adpcm.PSX_AUDIO_XA_FORMAT_XACD, True, 37800, 4, 1, 0)
+    sps = adpcm.xa_get_samples_per_sector(settings)
+    n_ch, n_sectors = 8, 3600 * 37800 // sps
+    assert n_sectors == 67500 and n_ch * n_sectors == 540000
+    n = n_sectors * sps
+    dev = torch.device("cuda", 0)
+    pcm = torch.empty((n_ch, n * 2), dtype=torch.int16, device=dev)
+    for c in range(n_ch):
+        for side in range(2):
+            # loud two-tone + noise, quiet tone, full-scale noise, half-silent -- a different class per chain
+            synth.pcm_device(1, 2 * c + side, 0, n, (0, 1, 2, 5)[(2 * c + side) % 4], device=0, out=pcm[c][side:], pitch=2)
+    chains = adpcm.make_chains([c * n * 2 + side for c in range(n_ch) for side in range(2)], 2, n, n_sectors * 72, unit_stride=2)
+    base = np.array([c * n_sectors * 144 + side for c in range(n_ch) for side in range(2)], np.int32)
+    chunk_units, warmup_units = adpcm.pick_chunking(int(chains["n_units"].sum()))
+    sess = adpcm.AdpcmSession(pcm.reshape(-1), chains, base, 4, 4, chunk_units=chunk_units, warmup_units=warmup_units)
+    run_time_sharded(sess, 0, 1, None, np.zeros((2 * n_ch, 2), np.int32))
+    outs = [adpcm.xa_assemble_device(sess.d_units[c * n_sectors * 144:], n_sectors, settings, first_lba=150 + c * n_sectors) for c in range(n_ch)]
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy() for o in outs]
+    host_pcm = pcm.cpu().numpy()
+    sess.close()
+    del pcm, outs
+
+    use_ref = O.ref() is not None
+    os_ = O.XaSettings(1, 1, 37800, 4, 1, 0)
+    bad = {}
+
+    def check(c):
+        x = np.concatenate([host_pcm[c], np.zeros(8064, np.int16)])
+        enc = O.ref_xa_encode if use_ref else O.xa_encode
+        want, _ = enc(os_, x, n, lba=150 + c * n_sectors)
+        w = want.reshape(n_sectors, 2352)
+        if not np.array_equal(got[c], w):
+            bad[c] = np.nonzero((got[c] != w).any(axis=1))[0][:5].tolist()
+
+    ths = [threading.Thread(target=check, args=(c,)) for c in range(n_ch)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not bad, "sectors differ from the %s: %s" % ("reference build" if use_ref else "oracle", bad)
+    # properties on everything: sync pattern, BCD time code of lba 150 + k, mode 2, subheader twice, EDC over 0x10..0x92B
+    for c in (0, 7):
+        g = got[c]
+        assert (g[:, 0] == 0).all() and (g[:, 1:11] == 0xFF).all() and (g[:, 11] == 0).all() and (g[:, 15] == 2).all()
+        lba = 150 + c * n_sectors + np.arange(n_sectors)
+        m, s_, f = lba // 4500, (lba // 75) % 60, lba % 75
+        bcd = lambda v: ((v // 10) << 4) | (v % 10)
+        assert np.array_equal(g[:, 12], bcd(m)) and np.array_equal(g[:, 13], bcd(s_)) and np.array_equal(g[:, 14], bcd(f))
+        assert np.array_equal(g[:, 16:20], g[:, 20:24]) and (g[:, 18] == 0x64).all()
+        for k in range(0, n_sectors, 337):
+            edc = O.lib().orc_edc_crc32(O.ptr(np.ascontiguousarray(g[k, 16:0x92C]), O.u8p), 0x92C - 16)
+            assert int.from_bytes(g[k, 0x92C:0x930].tobytes(), "little") == edc

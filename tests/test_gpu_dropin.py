@@ -214,10 +214,11 @@ def test_c_example_program_builds_runs_and_matches_oracle(tmp_path):
     assert rc == 0 and np.array_equal(data, want)
 
 
-def _oracle_str_stream(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm, channels=2, freq=37800, bits=4,
+def _oracle_str_stream_complete(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm, channels=2, freq=37800, bits=4,
                        trailing=False, n_sectors=None):
-    """the sector loop of encode_file_str (filefmt.c:450-503) over the oracle's restatements, sector buffers zeroed
-    first; ends with the last frame's last sector, EOF on the last audio sector."""
+    """PSXHIP_STR_TAIL_COMPLETE: the sector loop of encode_file_str (filefmt.c:450-503) over the oracle's restatements with
+    the end-of-input rules replaced -- every frame is encoded, the stream ends with the last frame's last sector, EOF on the
+    last audio sector only.  (The reference's own tail is tests/str_reference_loop.py.)"""
     n_frames = frames.shape[0]
     ofmt = {6: O.FMT_STR, 7: O.FMT_STRCD, 9: O.FMT_STRV}[fmt]
     oxs = O.XaSettings(1 if fmt == 7 else 0, 1 if channels == 2 else 0, freq, bits, 1, 0)
@@ -281,12 +282,62 @@ def _oracle_str_stream(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm
 
 @pytest.mark.parametrize("fmt,codec,w,h,n_frames,channels", [(7, 0, 320, 240, 160, 2), (6, 1, 160, 112, 40, 1), (9, 2, 96, 64, 30, 0),
                                                             (7, 0, 320, 240, 240, 2)])     # 2400 sectors: the threaded interleave
-def test_batched_str_mux_whole_stream_vs_oracle_loop(fmt, codec, w, h, n_frames, channels):
-    """psxhip_str_encode_host (product code: one batched MDEC launch + one XA stream + host interleave) against the
-    reference's sector-by-sector loop restated over the oracle, whole stream, for config 'strcd v2' (160 frames) and the
-    other two STR flavours."""
+def test_batched_str_mux_whole_stream_vs_reference_loop(fmt, codec, w, h, n_frames, channels):
+    """psxhip_str_encode_host (product code: one batched MDEC call + one XA stream + host interleave), default tail =
+    the reference's, against encode_file_str restated call for call over the oracle with its decoder's end-of-input model
+    (tests/str_reference_loop.py: filefmt.c:391-520, decoding.c:510-586), whole stream, for config 'strcd v2' (160 frames)
+    and the other two STR flavours."""
+    import str_reference_loop as R
     from psxavenc_amd import strmux
     s = strmux.settings(fmt=fmt, codec=codec, width=w, height=h, channels=channels, frequency=37800, bits=4)
+    frames = O.synth_frames(w, h, n_frames, seed=21, amp=6)
+    if channels:
+        pl = strmux.plan(s, n_frames)
+        n = (pl.n_audio_sectors + 2) * pl.audio_samples_per_sector + 100      # a little more audio than video
+        pcm = np.zeros(n * channels, np.int16)
+        for c in range(channels):
+            pcm[c::channels] = O.synth_pcm(9, c, 0, n, 0)
+    else:
+        pcm = np.zeros(0, np.int16)
+    got, p2 = strmux.encode(s, frames, pcm)
+    want, qsum, frames_encoded = R.encode_file_str(fmt, codec, w, h, 15, 1, 2, frames, pcm, channels=channels)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
+    assert p2.quant_scale_sum == qsum and p2.n_frames_encoded == frames_encoded == n_frames - 2
+    if channels:        # every audio sector after the decoder saw the end carries EOF; more than one does
+        sub = 0x12 if fmt == 7 else 0x02
+        rows = strmux.plan_sectors(s, n_frames, pcm.size // channels)
+        eof = [int(got[k, sub] >> 7) for k in np.nonzero(rows[:, 0] == 1)[0]]
+        assert eof == rows[rows[:, 0] == 1, 3].tolist() and sum(eof) >= 1 and eof[0] == 0
+
+
+@pytest.mark.parametrize("n_audio_sectors_x10", [0, 5, 30, 87])
+def test_batched_str_mux_audio_shorter_than_video(n_audio_sectors_x10):
+    """the reference's stream ends with whichever input ends first (decoding.c:540-553): audio of 0 / 0.5 / 3 / 8.7 sectors
+    against 24 frames of video -- short last sector completed from the decoder's zero padding, empty audio slots, EOF flags"""
+    import str_reference_loop as R
+    from psxavenc_amd import strmux
+    w, h, n_frames = 160, 112, 24
+    s = strmux.settings(fmt=7, codec=0, width=w, height=h)
+    frames = O.synth_frames(w, h, n_frames, seed=5, amp=6)
+    n = 2016 * n_audio_sectors_x10 // 10
+    pcm = np.zeros(2 * n, np.int16)
+    for c in range(2):
+        pcm[c::2] = O.synth_pcm(11, c, 0, n, 0)
+    got, p = strmux.encode(s, frames, pcm)
+    want, qsum, frames_encoded = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames, pcm)
+    assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape)
+    assert (p.quant_scale_sum, p.n_frames_encoded) == (qsum, frames_encoded)
+    assert frames_encoded < n_frames - 2            # the audio ended the stream
+
+
+@pytest.mark.parametrize("fmt,codec,w,h,n_frames,channels", [(7, 0, 320, 240, 160, 2), (6, 1, 160, 112, 40, 1), (9, 2, 96, 64, 30, 0)])
+def test_batched_str_mux_complete_tail(fmt, codec, w, h, n_frames, channels):
+    """PSXHIP_STR_TAIL_COMPLETE (every frame in the stream, EOF on the last audio sector, silence when the audio runs out):
+    the convention of the earlier rounds, reachable by flag only; config 'strcd v2' stays pinned by its SHA-256"""
+    from psxavenc_amd import strmux
+    s = strmux.settings(fmt=fmt, codec=codec, width=w, height=h, channels=channels, frequency=37800, bits=4, tail=strmux.TAIL_COMPLETE)
     frames = O.synth_frames(w, h, n_frames, seed=21, amp=6)
     p = strmux.plan(s, n_frames)
     if channels:
@@ -297,14 +348,71 @@ def test_batched_str_mux_whole_stream_vs_oracle_loop(fmt, codec, w, h, n_frames,
     else:
         pcm = np.zeros(0, np.int16)
     got, p2 = strmux.encode(s, frames, pcm)
-    want, qsum = _oracle_str_stream(fmt, codec, w, h, 15, 1, 2, frames, pcm, channels=channels)
+    want, qsum = _oracle_str_stream_complete(fmt, codec, w, h, 15, 1, 2, frames, pcm, channels=channels)
     assert got.shape == want.shape, (got.shape, want.shape)
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
-    assert p2.quant_scale_sum == qsum
+    assert p2.quant_scale_sum == qsum and p2.n_frames_encoded == n_frames
     if fmt == 7 and n_frames == 160:
         b = strmux.frame_budgets(s, 0, 5).tolist()
         assert b == [16128, 18144, 18144, 18144, 16128]
         import hashlib
         # pinned: 160 frames of config 'strcd v2' (seed 21, noise +-6) = 1600 sectors
         assert hashlib.sha256(got.tobytes()).hexdigest() == "f2eb7256f1a0e02d681d030651011cfeb9d0ee7cf2c59687a68f579d2b697add"
+
+
+def test_str_handles_are_independent_and_multi_device_equals_single():
+    """no process-global state: two muxer handles with different geometries used alternately and from two threads; a handle
+    over the device list {0, 0} (two encoder contexts on one GPU) produces the single-device stream byte for byte"""
+    import threading
+    from psxavenc_amd import strmux
+    a, b, ab = strmux.StrMuxer((0,)), strmux.StrMuxer((0,)), strmux.StrMuxer((0, 0))
+    sa = strmux.settings(fmt=7, codec=0, width=320, height=240)
+    sb = strmux.settings(fmt=6, codec=1, width=96, height=64, channels=1)
+    fa = O.synth_frames(320, 240, 50, seed=2, amp=6)
+    fb = O.synth_frames(96, 64, 30, seed=3, amp=6)
+    pa = np.zeros(2 * 2016 * 80, np.int16)
+    pa[0::2] = O.synth_pcm(1, 0, 0, 2016 * 80, 0)
+    pa[1::2] = O.synth_pcm(1, 1, 0, 2016 * 80, 0)
+    pb = O.synth_pcm(2, 0, 0, 4032 * 40, 0)
+    ra, _ = a.encode(sa, fa, pa)
+    rb, _ = b.encode(sb, fb, pb)
+    r2, _ = ab.encode(sa, fa, pa)
+    assert np.array_equal(r2, ra)
+    assert np.array_equal(ab.encode(sb, fb, pb)[0], rb)          # geometry change on one handle
+    assert np.array_equal(ab.encode(sa, fa, pa)[0], ra)
+    res = {}
+
+    def work(name, m, s, f, p):
+        for _ in range(3):
+            res[name] = m.encode(s, f, p)[0]
+
+    ths = [threading.Thread(target=work, args=("a", a, sa, fa, pa)), threading.Thread(target=work, args=("b", b, sb, fb, pb))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert np.array_equal(res["a"], ra) and np.array_equal(res["b"], rb)
+    for m in (a, b, ab):
+        m.close()
+
+
+def test_strcd_config3_at_1000_frames():
+    """BASELINE config 3 at its full size: 1000 frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA, 2x -> STRCD sectors,
+    the reference's tail; whole stream against the reference loop over the oracle"""
+    import str_reference_loop as R
+    from psxavenc_amd import strmux
+    w, h, n_frames = 320, 240, 1000
+    s = strmux.settings()
+    frames = O.synth_frames(w, h, n_frames, seed=1, amp=4)
+    n = 2016 * 1260
+    pcm = np.zeros(2 * n, np.int16)
+    for c in range(2):
+        pcm[c::2] = O.synth_pcm(1, c, 0, n, 0)
+    got, p = strmux.encode(s, frames, pcm)
+    assert p.n_frames_encoded == 998 and p.n_sectors == got.shape[0]
+    want, qsum, frames_encoded = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames, pcm)
+    assert got.shape == want.shape
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
+    assert (p.quant_scale_sum, frames_encoded) == (qsum, 998)

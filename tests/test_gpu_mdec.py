@@ -42,7 +42,7 @@ def test_library_is_the_hip_build():
 
 
 def test_selfgolden_matrix_all_cases():
-    """every (codec, size, budget, content) case of the committed matrix, against hashes AND the live oracle"""
+    """every (codec, size, budget, content) case of the committed matrix, against the committed hashes AND the live oracle"""
     g = np.load(GOLD)
     from psxavenc_amd import _lib
     for row in g["table"]:
@@ -55,6 +55,9 @@ def test_selfgolden_matrix_all_cases():
             assert e.value.code == _lib.PSXHIP_ENOFIT
         else:
             out, res = enc.encode_frames_host(fr, budget)
+            want, want_res, orc = O.mdec_encode(codec, w, h, fr, budget)
+            assert orc == 0
+            assert_same(out, res, want, want_res, str(row[:7]))
             assert res.ravel().tolist() == row[7:7 + 4 * n].tolist(), row[:7]
             assert hashlib.sha256(out.tobytes()).digest() == g["sha_c%d_%dx%d_b%d_a%d" % (codec, w, h, budget, amp)].tobytes(), row[:7]
         enc.close()
@@ -464,3 +467,94 @@ def test_single_frame_calls_follow_the_content(torch_cuda, monkeypatch):
     for k in (1, 3, 4, 6):                   # the second call on the same content starts from the right scale ...
         assert seen[k][0] == seen[k][1], seen
     assert seen[2][0] == calm_scale and seen[5][0] == busy_scale, seen      # ... the first one after a cut from the old one
+
+
+# ---------------------------------------------------------------- several devices behind one call (psxhip_multi.cpp)
+@pytest.mark.parametrize("schedule,ticket", [(0, 0), (1, 0), (1, 100)])
+def test_multi_device_list_equals_single_device(schedule, ticket):
+    """psxhip_mdec_multi_encode_frames_host over the device list {0, 0} (two contexts, two host threads, one GPU): bytes and
+    results of the single-device call, for contiguous ranges and for the host ticket queue, uniform and per-frame budgets"""
+    from psxavenc_amd import multi
+    w, h, n = 320, 240, 1500
+    fr = np.concatenate([O.synth_frames(w, h, n // 2, seed=1, amp=4), O.synth_frames(w, h, n - n // 2, seed=2, amp=8)])
+    single = encoder(0, w, h, 18144)
+    m = multi.MdecMulti((0, 0), 0, w, h, 18144)
+    want, want_res = single.encode_frames_host(fr, 8192)
+    got, got_res = m.encode_frames_host(fr, 8192, schedule=schedule, ticket_frames=ticket)
+    assert_same(got, got_res, want, want_res, "multi uniform")
+    rep = m.last_report
+    assert sum(r["units"] for r in rep) == n and all(r["device"] == 0 for r in rep)
+    if schedule == 1 and ticket:
+        assert sum(r["tickets"] for r in rep) == -(-n // ticket)
+    # per-frame budgets (the STR cycle): rows are as wide as the batch's largest budget in every sub-range
+    budgets = np.array([16128, 18144, 18144, 18144] * (n // 4), np.int32)
+    budgets[: n // 2] = 16128                              # a sub-range whose own maximum is smaller than the batch's
+    want, want_res = single.encode_frames_host(fr, budgets, out=np.full((n, 18144), 0xAA, np.uint8))
+    got, got_res = m.encode_frames_host(fr, budgets, schedule=schedule, ticket_frames=ticket, out=np.full((n, 18144), 0xAA, np.uint8))
+    assert_same(got, got_res, want, want_res, "multi per-frame budgets")
+    ow, owr, rc = O.mdec_encode(0, w, h, fr[::97], budgets[::97], stride=18144)
+    assert rc == 0
+    assert_same(got[::97], got_res[::97], ow, owr, "multi vs oracle")
+    single.close()
+    m.close()
+
+
+def test_multi_reports_no_fit_like_the_single_device_call():
+    from psxavenc_amd import _lib, multi
+    w, h = 64, 48
+    rng = np.random.default_rng(5)
+    fr = O.synth_frames(w, h, 40, seed=9, amp=4)
+    fr[23] = rng.integers(0, 256, fr.shape[1], dtype=np.uint8)           # white noise: fits no scale at this budget
+    m = multi.MdecMulti((0, 0, 0), 0, w, h, 400)
+    with pytest.raises(_lib.PsxHipError) as e:
+        m.encode_frames_host(fr, 400)
+    assert e.value.code == _lib.PSXHIP_ENOFIT and "frame 23" in str(e.value)
+    m.close()
+
+
+# ---------------------------------------------------------------- production shapes at production batch sizes
+def _check_frame_properties(out, res, version, budget):
+    assert ((res[:, 0] >= 1) & (res[:, 0] <= 63)).all()
+    assert (out[:, 2] == 0).all() and (out[:, 3] == 0x38).all() and (out[:, 6] == version).all() and (out[:, 7] == 0).all()
+    assert np.array_equal(out[:, 4].astype(np.int32) | (out[:, 5].astype(np.int32) << 8), res[:, 0])
+    assert np.array_equal(out[:, 0].astype(np.int32) | (out[:, 1].astype(np.int32) << 8), res[:, 2])
+    assert (res[:, 1] <= budget).all() and (res[:, 1] % 4 == 0).all()
+    col = np.arange(out.shape[1])[None, :]
+    assert not (out * (col >= res[:, 1:2])).any()          # zero tail after bytes_used
+
+
+@pytest.mark.parametrize("w,h,budget,n,amp,tile,what", [
+    (640, 480, 8192, 1250, 4, 2048, "config 'sbs v3': one GPU's share, 8 KiB budgets -> 2 KiB image tile"),
+    (640, 448, 8192, 640, 4, 4096, "4 KiB image tile"),
+    (640, 480, 32768, 600, 8, None, "32 KiB budgets: one 16-wavefront group per CU"),
+])
+def test_production_shapes_in_one_launch(torch_cuda, w, h, budget, n, amp, tile, what):
+    """BS v3 at the shapes a full batch really runs in -- asserted through psxhip_mdec_query_geometry: 12 wavefronts, two
+    groups per CU and the small image tiles for 8 KiB budgets (a launch of > 256 frames, so not the small-batch shape) --
+    every 8th frame byte for byte against the oracle, header / tail / result properties on all, a few decoded back."""
+    torch = torch_cuda
+    from psxavenc_amd import synth
+    from psxavenc_amd.mdec import query_geometry
+    g = query_geometry(1, w, h, budget)
+    assert g.fits
+    if tile is not None:
+        assert (g.groups_per_cu, g.wavefronts_per_group, g.image_tile_bytes) == (2, 12, tile), (what, g.groups_per_cu, g.wavefronts_per_group, g.image_tile_bytes)
+    else:
+        assert (g.groups_per_cu, g.wavefronts_per_group) == (1, 16)
+    assert n > 256 and n > g.frames_in_flight
+    enc = encoder(1, w, h, budget)
+    d_frames = synth.frames_device(w, h, seed=2, first=1250 * 3, n=n, amp=amp, device=0)
+    d_out, d_res = enc.encode_frames_device(d_frames, budget)
+    torch.cuda.synchronize()
+    out, res = d_out.cpu().numpy()[:, :budget], d_res.cpu().numpy()
+    _check_frame_properties(out, res, 3, budget)
+    idx = list(range(0, n, 8))
+    fr = d_frames[idx].cpu().numpy()
+    want, want_res, rc = O.mdec_encode(1, w, h, fr, budget)
+    assert rc == 0
+    assert_same(out[idx], res[idx], want, want_res, what)
+    for k in idx[:3]:
+        rc2, levels, scale, version, nbits = O.mdec_decode(w, h, out[k])
+        assert rc2 == 0 and version == 3 and scale == res[k, 0]
+        assert res[k, 1] == ((8 + 2 * ((nbits + 15) // 16) + 3) & ~3)
+    enc.close()

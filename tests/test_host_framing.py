@@ -12,10 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_str_plan_and_budgets_config_strcd():
     """config 'strcd v2' (SURVEY 3.2): 320x240 @15 fps, 2x, 37800 Hz 4-bit stereo: interleave 8, budgets cycling
-    16128 / 18144 x3 (mdec.c:768-775), stream ends with the last frame's last sector (filefmt.c:450)"""
+    16128 / 18144 x3 (mdec.c:768-775).  COMPLETE tail: the stream ends with the last frame's last sector; REFERENCE tail
+    (default): the CLI's loop stops once <= frames_needed = 2 frames are left (filefmt.c:443-450)"""
     from psxavenc_amd import strmux
     from psxavenc_amd.parallel import str_frame_budgets
-    s = strmux.settings()
+    s = strmux.settings(tail=strmux.TAIL_COMPLETE)
     p = strmux.plan(s, 160)
     assert (p.interleave, p.sector_size, p.audio_samples_per_sector, p.max_frame_size) == (8, 2352, 2016, 18144)
     b = strmux.frame_budgets(s, 0, 160)
@@ -23,15 +24,76 @@ def test_str_plan_and_budgets_config_strcd():
     assert b.tolist() == str_frame_budgets(160, 75 * 2 * 7 * 1, 8 * 15)
     assert strmux.frame_budgets(s, 37, 9).tolist() == b[37:46].tolist()          # any rank can budget its own range
     assert p.n_video_sectors == int(b.sum()) // 2016 == 1400
-    assert p.n_sectors == 1600 and p.n_audio_sectors == 200
+    assert p.n_sectors == 1600 and p.n_audio_sectors == 200 and p.n_frames_encoded == 160
+    # the reference's tail: 158 of the 160 frames, and the budgets do not depend on the tail
+    r = strmux.plan(strmux.settings(), 160)
+    assert r.n_frames_encoded == 158 and r.n_video_sectors == int(b[:158].sum()) // 2016
+    assert strmux.frame_budgets(strmux.settings(), 0, 160).tolist() == b.tolist()
     # video only (strv): every sector is video, 2336-byte sectors
-    v = strmux.plan(strmux.settings(fmt=strmux.FORMAT_STRV, channels=0), 30)
+    v = strmux.plan(strmux.settings(fmt=strmux.FORMAT_STRV, channels=0, tail=strmux.TAIL_COMPLETE), 30)
     assert v.n_audio_sectors == 0 and v.n_sectors == v.n_video_sectors and v.sector_size == 2336 and v.interleave == 1
     # trailing audio: the audio sector closes each block
-    t = strmux.plan(strmux.settings(trailing_audio=True), 160)
+    t = strmux.plan(strmux.settings(trailing_audio=True, tail=strmux.TAIL_COMPLETE), 160)
     assert t.n_video_sectors == 1400 and t.n_sectors == 1599
     with pytest.raises(Exception):
         strmux.plan(strmux.settings(width=321), 4)
+    with pytest.raises(Exception):
+        strmux.plan(strmux.settings(tail=7), 4)
+
+
+def _stream_structure(stream, fmt):
+    """(kind, frame, index, eof) per sector, read back from the bytes the reference's loop produced"""
+    at = {6: 0x08, 7: 0x18, 9: 0x00}[fmt]
+    sub = 0x12 if fmt == 7 else 0x02
+    rows = []
+    audio = 0
+    for sec in stream:
+        if sec[at] == 0x60 and sec[at + 1] == 0x01:                      # STR chunk header, mdec.c:786-787
+            frame = int(sec[at + 8]) | int(sec[at + 9]) << 8 | int(sec[at + 10]) << 16
+            rows.append((0, frame - 1, int(sec[at + 4]) | int(sec[at + 5]) << 8, 0))
+        elif not sec.any():
+            rows.append((2, -1, -1, 0))
+        else:
+            rows.append((1, -1, audio, int(sec[sub] >> 7)))
+            audio += 1
+    return np.array(rows, np.int32).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("fmt,channels,bits,freq,speed,fps,trailing", [
+    (7, 2, 4, 37800, 2, (15, 1), False),      # config 'strcd v2'
+    (7, 2, 4, 37800, 2, (15, 1), True),
+    (6, 1, 4, 37800, 2, (15, 1), False),
+    (6, 2, 8, 18900, 1, (10, 1), False),
+    (9, 0, 4, 37800, 2, (15, 1), False),
+    (7, 2, 4, 37800, 2, (30000, 1001), False),
+    (6, 1, 8, 37800, 2, (25, 1), True),
+])
+def test_str_plan_follows_the_reference_sector_loop(oracle, fmt, channels, bits, freq, speed, fps, trailing):
+    """psxhip_str_plan_sectors (the product's dry run of the sector loop, REFERENCE tail) against the structure of the
+    stream that encode_file_str restated over the oracle (tests/str_reference_loop.py, filefmt.c:391-520 + decoding.c:510-586)
+    produces: which sector is video / audio / an empty audio slot, frame and chunk numbers, EOF flags, where the stream
+    ends -- for plenty of audio, audio that ends first (incl. mid-sector and exactly on a sector), and tiny inputs."""
+    import str_reference_loop as R
+    from psxavenc_amd import strmux
+    w, h = 16, 16                              # the structure does not depend on the picture
+    s = strmux.settings(fmt=fmt, codec=0, width=w, height=h, fps_num=fps[0], fps_den=fps[1], cd_speed=speed,
+                        trailing_audio=trailing, channels=channels, frequency=freq, bits=bits)
+    sps = strmux.plan(s, 4).audio_samples_per_sector
+    for n_frames in (1, 2, 3, 4, 7, 24):
+        frames = oracle.synth_frames(w, h, n_frames, seed=3, amp=2)
+        lengths = [0] if not channels else [10 ** 6, 0, 1, sps - 1, sps, sps + 1, 2 * sps, 3 * sps + 77, 7 * sps]
+        for n_audio in lengths:
+            pcm = np.zeros(n_audio * max(1, channels), np.int16)
+            pcm[:] = (np.arange(pcm.size) * 37 % 2001 - 1000)
+            want, _, frames_encoded = R.encode_file_str(fmt, 0, w, h, fps[0], fps[1], speed, frames, pcm, channels=channels, freq=freq,
+                                                        bits=bits, trailing_audio=trailing)
+            got = strmux.plan_sectors(s, n_frames, n_audio)
+            p = strmux.plan(s, n_frames, n_audio)
+            ctx = (n_frames, n_audio)
+            assert got.shape[0] == want.shape[0] == p.n_sectors, ctx
+            assert p.n_frames_encoded == frames_encoded, ctx
+            ws = _stream_structure(want, fmt)
+            assert np.array_equal(got, ws), (ctx, np.nonzero((got != ws).any(axis=1))[0][:5])
 
 
 def test_spu_file_sizes_match_reference_golden():

@@ -6,7 +6,7 @@ from psxavenc_amd import _lib
 
 class Geo(C.Structure):
     _fields_ = [("fits", C.c_int32), ("groups_per_cu", C.c_int32), ("wavefronts_per_group", C.c_int32), ("frames_in_flight", C.c_int32),
-                ("max_frame_size_limit", C.c_int32), ("reserved", C.c_int32), ("lds_bytes_per_group", C.c_int64), ("lds_bytes_per_cu", C.c_int64)]
+                ("max_frame_size_limit", C.c_int32), ("image_tile_bytes", C.c_int32), ("lds_bytes_per_group", C.c_int64), ("lds_bytes_per_cu", C.c_int64)]
 
 
 for (w, h, b) in ((320, 240, 8192), (320, 240, 18144), (640, 480, 8192), (640, 480, 32768), (640, 512, 20160), (160, 112, 4096), (16, 16, 64)):
