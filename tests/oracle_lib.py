@@ -157,7 +157,7 @@ def mdec_encode(codec, w, h, frames, budgets, stride=None):
     Returns (out (n, stride) u8, results (n, 4) int32 [scale, bytes, blocks, hwords], rc)."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     n = frames.shape[0]
-    budgets = np.full(n, budgets, dtype=np.int32) if np.isscalar(budgets) else np.asarray(budgets, dtype=np.int32)
+    budgets = np.full(n, budgets, dtype=np.int32) if np.isscalar(budgets) else np.ascontiguousarray(budgets, dtype=np.int32)
     stride = int(budgets.max()) if stride is None else stride
     out = np.zeros((n, stride), dtype=np.uint8)
     res = (MdecResult * n)()

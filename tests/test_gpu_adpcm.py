@@ -499,7 +499,7 @@ def test_xacd_config5_full_size_every_sector_against_the_reference():
     for c in (0, 7):
         g = got[c]
         assert (g[:, 0] == 0).all() and (g[:, 1:11] == 0xFF).all() and (g[:, 11] == 0).all() and (g[:, 15] == 2).all()
-        lba = 150 + c * n_sectors + np.arange(n_sectors)
+        lba = 150 + (150 + c * n_sectors + np.arange(n_sectors))      # psx_cdrom_init_sector adds the 2-second lead-in (cdrom.c:62)
         m, s_, f = lba // 4500, (lba // 75) % 60, lba % 75
         bcd = lambda v: ((v // 10) << 4) | (v % 10)
         assert np.array_equal(g[:, 12], bcd(m)) and np.array_equal(g[:, 13], bcd(s_)) and np.array_equal(g[:, 14], bcd(f))

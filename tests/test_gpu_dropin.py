@@ -309,7 +309,8 @@ def test_batched_str_mux_whole_stream_vs_reference_loop(fmt, codec, w, h, n_fram
         sub = 0x12 if fmt == 7 else 0x02
         rows = strmux.plan_sectors(s, n_frames, pcm.size // channels)
         eof = [int(got[k, sub] >> 7) for k in np.nonzero(rows[:, 0] == 1)[0]]
-        assert eof == rows[rows[:, 0] == 1, 3].tolist() and sum(eof) >= 1 and eof[0] == 0
+        assert eof == rows[rows[:, 0] == 1, 3].tolist() and eof[0] == 0
+        assert sum(eof) >= 1 or channels == 1       # (mono: one sector in 16 is audio, the tail may hold none)
 
 
 @pytest.mark.parametrize("n_audio_sectors_x10", [0, 5, 30, 87])

@@ -492,7 +492,7 @@ def test_multi_device_list_equals_single_device(schedule, ticket):
     want, want_res = single.encode_frames_host(fr, budgets, out=np.full((n, 18144), 0xAA, np.uint8))
     got, got_res = m.encode_frames_host(fr, budgets, schedule=schedule, ticket_frames=ticket, out=np.full((n, 18144), 0xAA, np.uint8))
     assert_same(got, got_res, want, want_res, "multi per-frame budgets")
-    ow, owr, rc = O.mdec_encode(0, w, h, fr[::97], budgets[::97], stride=18144)
+    ow, owr, rc = O.mdec_encode(0, w, h, fr[::97], np.ascontiguousarray(budgets[::97]), stride=18144)
     assert rc == 0
     assert_same(got[::97], got_res[::97], ow, owr, "multi vs oracle")
     single.close()
@@ -524,8 +524,8 @@ def _check_frame_properties(out, res, version, budget):
 
 
 @pytest.mark.parametrize("w,h,budget,n,amp,tile,what", [
-    (640, 480, 8192, 1250, 4, 2048, "config 'sbs v3': one GPU's share, 8 KiB budgets -> 2 KiB image tile"),
-    (640, 448, 8192, 640, 4, 4096, "4 KiB image tile"),
+    (640, 480, 8192, 1250, 4, 4096, "config 'sbs v3': one GPU's share, 8 KiB budgets -> 4 KiB image tile"),
+    (640, 512, 8192, 640, 4, 2048, "the CLI's largest frame (args.c:410-421) at 8 KiB budgets -> 2 KiB image tile"),
     (640, 480, 32768, 600, 8, None, "32 KiB budgets: one 16-wavefront group per CU"),
 ])
 def test_production_shapes_in_one_launch(torch_cuda, w, h, budget, n, amp, tile, what):

@@ -129,3 +129,31 @@ def test_batched_callers_fail_loudly_without_a_device():
     L.psxhip_mdec_fdct_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     b = np.zeros(64, np.int16)
     assert L.psxhip_mdec_fdct_host(0, b.ctypes.data, 1, b.ctypes.data) == _lib.PSXHIP_EDEVICE
+
+
+def test_fdct_pin_kit_still_compiles_against_its_declared_ffmpeg_surface(tmp_path):
+    """tools/check_fdct_vs_ffmpeg.c is the one way to close the MDEC parity gap (the FDCT is FFmpeg's, mdec.c:640) and it
+    cannot be built here (no FFmpeg).  Keep it from rotting: -fsyntax-only against a prototype list of exactly the FFmpeg
+    surface it uses -- written down HERE as part of the test, not shipped as headers -- plus the repository's real headers
+    for everything else (oracle/mdec_oracle.h, include/psxav_hip.h)."""
+    import subprocess
+    inc = tmp_path / "inc"
+    (inc / "libavcodec").mkdir(parents=True)
+    (inc / "libavutil").mkdir()
+    (inc / "libavcodec" / "avcodec.h").write_text("unsigned avcodec_version(void);\nconst char *avcodec_configuration(void);\n#define FF_DCT_INT 2\n")
+    (inc / "libavcodec" / "avdct.h").write_text(
+        "#include <stdint.h>\n#include <stddef.h>\n"
+        "typedef struct AVDCT { const void *av_class; void (*idct)(int16_t *block); void (*fdct)(int16_t *block);\n"
+        "  int dct_algo; int idct_algo; void (*get_pixels)(int16_t *block, const uint8_t *pixels, ptrdiff_t line_size);\n"
+        "  int bits_per_sample; } AVDCT;\n"
+        "AVDCT *avcodec_dct_alloc(void);\nint avcodec_dct_init(AVDCT *);\n")
+    (inc / "libavcodec" / "version.h").write_text("#define LIBAVCODEC_IDENT \"Lavc (prototype list of the test)\"\n#define LIBAVCODEC_VERSION_MAJOR 0\n"
+                                                  "#define LIBAVCODEC_VERSION_MINOR 0\n#define LIBAVCODEC_VERSION_MICRO 0\n")
+    (inc / "libavutil" / "mem.h").write_text("void av_free(void *ptr);\n")
+    (inc / "libavutil" / "opt.h").write_text("#include <stdint.h>\nint av_opt_set_int(void *obj, const char *name, int64_t val, int search_flags);\n")
+    src = os.path.join(ROOT, "tools", "check_fdct_vs_ffmpeg.c")
+    for extra in ([], ["-DWITH_DEVICE"]):
+        r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-I", str(inc),
+                            "-I", os.path.join(ROOT, "oracle"), "-I", os.path.join(ROOT, "include"), src] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
