@@ -384,6 +384,37 @@ int64_t psxhip_spu_file_size(const psxhip_spu_file_settings_t *settings, int64_t
 int64_t psxhip_spu_file_encode_host(int device, const psxhip_spu_file_settings_t *settings, const int16_t *pcm,
                                     int64_t samples_per_channel, uint8_t *out, size_t out_size);
 
+/* ---------------------------------------------------------------- colour conversion + scaling front-end ---- */
+
+/* What the reference leaves to FFmpeg's libswscale (psxavenc/decoding.c:287-311: sws_getContext(... AV_PIX_FMT_NV21,
+ * SWS_BICUBIC ...), destination colourspace ITU-R BT.601 full range; :463-475: sws_scale into the frame buffer): decoded
+ * pictures of any size -> NV21 frames of the encoder's size, on the device, written where the MDEC kernel reads them.
+ * libswscale is absent from the reference tree and from the build image, so this step's arithmetic is this library's own
+ * ("psxhip front-end v1": bicubic B = 0 / C = 0.6 like SWS_BICUBIC, 14-bit taps, 15-bit intermediates; DESIGN.md section 9,
+ * restated in oracle/frontend_oracle.c) -- PARITY WITH THE REFERENCE'S SCALER IS UNPINNED.  Everything downstream of the NV21
+ * frames is unaffected. */
+enum {
+	PSXHIP_PIX_RGB24 = 0,      /* rows of 3 * width bytes, R G B */
+	PSXHIP_PIX_YUV420P = 1     /* Y plane (w * h), U plane, V plane ((w/2) * (h/2) each); w, h even */
+};
+typedef struct psxhip_scaler psxhip_scaler_t;
+/* src_full_range: YUV input only -- 0 = limited ("MPEG") range, expanded to the full range the encoder expects
+ * (decoding.c:301-311 passes the stream's own range as the source range); RGB input is full range by definition.
+ * dst_width / dst_height: multiples of 16 (mdec.c:601-602), at most 1024; shrinking by more than 16x is refused. */
+int psxhip_scaler_create(psxhip_scaler_t **s, int device, int src_format, int src_width, int src_height, int src_full_range,
+                         int dst_width, int dst_height);
+void psxhip_scaler_destroy(psxhip_scaler_t *s);
+size_t psxhip_scaler_source_bytes(const psxhip_scaler_t *s);      /* bytes of one source picture */
+/* n_frames pictures at d_src + i * src_stride -> NV21 frames at d_frames + i * frame_stride (4-byte aligned); asynchronous
+ * on `stream`.  d_frames / frame_stride are what psxhip_mdec_encode_frames_device takes. */
+int psxhip_scaler_convert_device(psxhip_scaler_t *s, const uint8_t *d_src, size_t src_stride, int n_frames, uint8_t *d_frames,
+                                 size_t frame_stride, void *stream);
+/* host buffers (pictures and frames back to back): H2D, kernel, D2H, synchronise */
+int psxhip_scaler_convert_host(psxhip_scaler_t *s, const uint8_t *src, int n_frames, uint8_t *frames);
+/* the filter banks in use (which: 0 luma horizontal, 1 luma vertical, 2 chroma horizontal, 3 chroma vertical): returns
+ * the number of output positions, *taps per position; fills left[n] / coef[n * taps] when both are given (cap elements) */
+int psxhip_scaler_filter(const psxhip_scaler_t *s, int which, int *taps, int32_t *left, int16_t *coef, int cap);
+
 /* ---------------------------------------------------------------- synthetic inputs --------- */
 
 /* Integer-only generators (same function as oracle/synth.c) so benchmarks can fill HBM directly. */

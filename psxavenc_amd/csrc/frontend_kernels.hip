@@ -1,0 +1,475 @@
+// frontend_kernels.hip -- colour conversion + scaling front-end for MI355X (gfx950): RGB24 / YUV420P pictures of any size
+// -> NV21 frames of the encoder's size, BT.601 full range, written straight into the buffer the MDEC kernel reads
+// (include/psxav_hip.h, psxhip_scaler_*).
+//
+// The reference hands this step to FFmpeg's libswscale (psxavenc/decoding.c:287-311: sws_getContext(... AV_PIX_FMT_NV21,
+// SWS_BICUBIC ...) + sws_setColorspaceDetails(dst = ITU-R BT.601, full range); :463-475: sws_scale into the frame buffer).
+// libswscale is not part of the reference tree and not installed here, so there is nothing to be bit-exact TO: the
+// arithmetic below is this library's own ("psxhip front-end v1", specified in DESIGN.md section 9 and restated
+// independently in oracle/frontend_oracle.c, which the tests hold this kernel to bit for bit).  It follows libswscale's
+// structure -- bicubic B = 0 / C = 0.6, taps widened when shrinking, 14-bit coefficients, a horizontal pass into 15-bit
+// intermediates, range expansion on the intermediates, a vertical pass -- so results agree with it to within the rounding
+// of those formats, but PARITY WITH THE REFERENCE'S SCALER IS UNPINNED and stays so until someone runs both side by side.
+//
+// Why it exists: the frame encoder consumes 750 GB/s of NV21 at its headline rate, a PCIe link delivers 50 GB/s.  Pictures
+// that are decoded on the device (or uploaded once at source size) have to become encoder input without leaving HBM.
+//
+// Mapping: HBM-bound streaming work, no matrix shape in it.  One workgroup = one tile of the OUTPUT (64 x 16 luma pixels +
+// the 32 x 8 chroma pairs under them) of one frame; grid = tiles x frames (>> 256 workgroups for any batch).  The source
+// region the tile's filters reach is read ONCE, coalesced, converted (RGB -> Y, Cb, Cr) and parked in LDS as bytes; the
+// horizontal pass runs LDS -> LDS (int16), the vertical pass LDS -> registers, and the tile leaves as dword stores (four
+// luma bytes, or two interleaved Cr,Cb pairs, per lane).  Filter taps of the tile's rows and columns sit in LDS too.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "psxhip_internal.h"
+
+int psxhip_ensure_device(int device);
+
+namespace {
+
+struct Bank {                 // one separable filter bank on the device
+    const int32_t* left;      // [n]
+    const int16_t* coef;      // [n * taps]
+    int taps;
+};
+
+struct ScalerJob {
+    const uint8_t* src;
+    size_t src_stride;
+    uint8_t* out;
+    size_t frame_stride;
+    int sw, sh, dw, dh;
+    int limited;              // YUV input in MPEG range: expand on the intermediates
+    Bank lh, lv, ch, cv;      // luma / chroma, horizontal / vertical
+    int csw, csh;             // chroma source plane size (sw/2 x sh/2 for YUV420P, sw x sh for RGB)
+    int TW, TH;               // luma tile; the chroma tile is TW/2 x TH/2
+    int tiles_x, tiles_y;
+    int reg_rows, reg_cols;   // LDS region capacity per plane (RGB: the union of the luma and chroma reach; YUV: luma)
+    int creg_rows, creg_cols; // ... of a chroma plane (YUV)
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The tap loops below carry `#pragma clang loop vectorize(disable) interleave(disable)`: hipcc 7.2 (LLVM 22git) versions the
+// vertical pass's loop for a unit row pitch, vectorises it, and the version it then runs with taps = 4 returned saturated
+// values for two of a lane's four outputs on the last three rows of every tile (enlarging 200x150 -> 320x240; found by
+// tests/test_gpu_frontend.py).  The loops are four to a few dozen trips of LDS reads and integer multiply-adds: there is
+// nothing for a vectoriser to win.
+
+template <int FMT>      // 0 = RGB24, 1 = YUV420P
+__global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = (int)threadIdx.x;
+    const int tx = (int)blockIdx.x % job.tiles_x, ty = (int)blockIdx.x / job.tiles_x;
+    const uint8_t* src = job.src + (size_t)blockIdx.y * job.src_stride;
+    uint8_t* out = job.out + (size_t)blockIdx.y * job.frame_stride;
+    const int TW = job.TW, TH = job.TH, CW = TW >> 1, CH = TH >> 1;
+
+    // ---- this tile's output ranges and the source ranges its taps reach
+    const int X0 = tx * TW, X1 = min(job.dw, X0 + TW), Y0 = ty * TH, Y1 = min(job.dh, Y0 + TH);
+    const int tw = X1 - X0, th = Y1 - Y0, cw = tw >> 1, chh = th >> 1;
+    const int cX0 = X0 >> 1, cY0 = Y0 >> 1;
+    const int lxa = job.lh.left[X0], lxb = job.lh.left[X1 - 1] + job.lh.taps;
+    const int lya = job.lv.left[Y0], lyb = job.lv.left[Y1 - 1] + job.lv.taps;
+    const int cxa = job.ch.left[cX0], cxb = job.ch.left[cX0 + cw - 1] + job.ch.taps;
+    const int cya = job.cv.left[cY0], cyb = job.cv.left[cY0 + chh - 1] + job.cv.taps;
+
+    // ---- LDS: three byte planes, the two intermediates, the tile's taps
+    const int plane_bytes = (job.reg_rows * job.reg_cols + 15) & ~15;
+    const int cplane_bytes = FMT == 0 ? plane_bytes : ((job.creg_rows * job.creg_cols + 15) & ~15);
+    uint8_t* p0 = (uint8_t*)smem;
+    uint8_t* p1 = p0 + plane_bytes;
+    uint8_t* p2 = p1 + cplane_bytes;
+    int16_t* tmpL = (int16_t*)(p2 + cplane_bytes);                               // [reg_rows][TW]
+    int16_t* tmpC = tmpL + (size_t)job.reg_rows * TW;                             // [2][crows][CW]
+    const int crows_cap = FMT == 0 ? job.reg_rows : job.creg_rows;
+    int16_t* f_lh = tmpC + (size_t)2 * crows_cap * CW;                            // [TW][taps]
+    int16_t* f_lv = f_lh + TW * job.lh.taps;
+    int16_t* f_ch = f_lv + TH * job.lv.taps;
+    int16_t* f_cv = f_ch + CW * job.ch.taps;
+    int32_t* l_all = (int32_t*)(((uintptr_t)(f_cv + CH * job.cv.taps) + 3) & ~(uintptr_t)3);    // lefts: [TW] [TH] [CW] [CH]
+    int32_t *l_lh = l_all, *l_lv = l_lh + TW, *l_ch = l_lv + TH, *l_cv = l_ch + CW;
+
+    for (int i = tid; i < tw * job.lh.taps; i += 256) f_lh[i] = job.lh.coef[(size_t)X0 * job.lh.taps + i];
+    for (int i = tid; i < th * job.lv.taps; i += 256) f_lv[i] = job.lv.coef[(size_t)Y0 * job.lv.taps + i];
+    for (int i = tid; i < cw * job.ch.taps; i += 256) f_ch[i] = job.ch.coef[(size_t)cX0 * job.ch.taps + i];
+    for (int i = tid; i < chh * job.cv.taps; i += 256) f_cv[i] = job.cv.coef[(size_t)cY0 * job.cv.taps + i];
+    if (tid < tw) l_lh[tid] = job.lh.left[X0 + tid];
+    if (tid < th) l_lv[tid] = job.lv.left[Y0 + tid];
+    if (tid < cw) l_ch[tid] = job.ch.left[cX0 + tid];
+    if (tid < chh) l_cv[tid] = job.cv.left[cY0 + tid];
+
+    // ---- stage the source region: every source byte of the region is read once (edge replication = clamped coordinates)
+    int ya, yb, xa, xb;          // the region of plane 0 (and, RGB, of all three)
+    int rcols, crcols;           // row pitch of the staged planes
+    if (FMT == 0) {
+        ya = min(lya, cya); yb = max(lyb, cyb); xa = min(lxa, cxa); xb = max(lxb, cxb);
+        rcols = xb - xa;
+        crcols = rcols;
+        const int rows = yb - ya;
+        // lane = one pixel; consecutive lanes read consecutive 3-byte pixels of a row
+        for (int item = tid; item < rows * rcols; item += 256) {
+            const int r = item / rcols, c = item - r * rcols;
+            const int sy = clampi(ya + r, 0, job.sh - 1), sx = clampi(xa + c, 0, job.sw - 1);
+            const uint8_t* px = src + ((size_t)sy * job.sw + sx) * 3;
+            const int R = px[0], G = px[1], B = px[2];
+            p0[item] = (uint8_t)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
+            p1[item] = (uint8_t)clampi(((-11059 * R - 21709 * G + 32768 * B + 32768) >> 16) + 128, 0, 255);     // Cb
+            p2[item] = (uint8_t)clampi(((32768 * R - 27439 * G - 5329 * B + 32768) >> 16) + 128, 0, 255);       // Cr
+        }
+    } else {
+        ya = lya; yb = lyb; xa = lxa; xb = lxb;
+        rcols = xb - xa;
+        crcols = cxb - cxa;
+        const uint8_t* Y = src;
+        const uint8_t* U = src + (size_t)job.sw * job.sh;
+        const uint8_t* V = U + (size_t)job.csw * job.csh;
+        for (int item = tid; item < (yb - ya) * rcols; item += 256) {
+            const int r = item / rcols, c = item - r * rcols;
+            p0[item] = Y[(size_t)clampi(ya + r, 0, job.sh - 1) * job.sw + clampi(xa + c, 0, job.sw - 1)];
+        }
+        for (int item = tid; item < (cyb - cya) * crcols; item += 256) {
+            const int r = item / crcols, c = item - r * crcols;
+            const size_t o = (size_t)clampi(cya + r, 0, job.csh - 1) * job.csw + clampi(cxa + c, 0, job.csw - 1);
+            p1[item] = U[o];      // Cb
+            p2[item] = V[o];      // Cr
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal pass, LDS -> LDS: 15-bit intermediates (+ the range expansion of limited-range input)
+    {
+        const int rows = lyb - lya, r_off = lya - ya, c_off = -xa, taps = job.lh.taps;
+        for (int item = tid; item < rows * tw; item += 256) {
+            const int r = item / tw, i = item - r * tw;
+            const uint8_t* row = p0 + (size_t)(r + r_off) * rcols + (l_lh[i] + c_off);
+            const int16_t* f = f_lh + i * taps;
+            int acc = 0;
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (int k = 0; k < taps; k++) acc += (int)f[k] * (int)row[k];
+            int t = clampi(acc >> 7, 0, 32767);
+            if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
+            tmpL[r * TW + i] = (int16_t)t;
+        }
+        const int crows = cyb - cya, cr_off = FMT == 0 ? cya - ya : 0, cc_off = FMT == 0 ? -xa : -cxa, ctaps = job.ch.taps;
+        for (int item = tid; item < 2 * crows * cw; item += 256) {
+            const int comp = item / (crows * cw), rem = item - comp * crows * cw;
+            const int r = rem / cw, i = rem - r * cw;
+            const uint8_t* row = (comp ? p1 : p2) + (size_t)(r + cr_off) * crcols + (l_ch[i] + cc_off);      // comp 0 = Cr, 1 = Cb
+            const int16_t* f = f_ch + i * ctaps;
+            int acc = 0;
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (int k = 0; k < ctaps; k++) acc += (int)f[k] * (int)row[k];
+            int t = clampi(acc >> 7, 0, 32767);
+            if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
+            tmpC[((size_t)comp * crows_cap + r) * CW + i] = (int16_t)t;
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass, LDS -> registers -> HBM: a lane makes four adjacent luma bytes / two adjacent Cr,Cb pairs
+    {
+        const int taps = job.lv.taps, q = tw >> 2;
+        for (int item = tid; item < th * q; item += 256) {
+            const int j = item / q, i4 = (item - j * q) * 4;
+            const int16_t* f = f_lv + j * taps;
+            const int16_t* col = tmpL + (size_t)(l_lv[j] - lya) * TW + i4;
+            int a0 = 1 << 20, a1 = 1 << 20, a2 = 1 << 20, a3 = 1 << 20;
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (int k = 0; k < taps; k++) {
+                const int c = (int)f[k];
+                const int16_t* t = col + k * TW;
+                a0 += c * (int)t[0]; a1 += c * (int)t[1]; a2 += c * (int)t[2]; a3 += c * (int)t[3];
+            }
+            const uint32_t v = (uint32_t)clampi(a0 >> 21, 0, 255) | (uint32_t)clampi(a1 >> 21, 0, 255) << 8 |
+                               (uint32_t)clampi(a2 >> 21, 0, 255) << 16 | (uint32_t)clampi(a3 >> 21, 0, 255) << 24;
+            *(uint32_t*)(out + (size_t)(Y0 + j) * job.dw + X0 + i4) = v;
+        }
+        const int ctaps = job.cv.taps, cq = cw >> 1;
+        uint8_t* cout = out + (size_t)job.dw * job.dh;
+        for (int item = tid; item < chh * cq; item += 256) {
+            const int j = item / cq, i2 = (item - j * cq) * 2;
+            const int16_t* f = f_cv + j * ctaps;
+            const int16_t* cr = tmpC + (size_t)(l_cv[j] - cya) * CW + i2;
+            const int16_t* cb = cr + (size_t)crows_cap * CW;
+            int r0 = 1 << 20, r1 = 1 << 20, b0 = 1 << 20, b1 = 1 << 20;
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (int k = 0; k < ctaps; k++) {
+                const int c = (int)f[k];
+                r0 += c * (int)cr[k * CW]; r1 += c * (int)cr[k * CW + 1];
+                b0 += c * (int)cb[k * CW]; b1 += c * (int)cb[k * CW + 1];
+            }
+            // NV21: Cr at even bytes, Cb at odd (mdec.c:627-628)
+            const uint32_t v = (uint32_t)clampi(r0 >> 21, 0, 255) | (uint32_t)clampi(b0 >> 21, 0, 255) << 8 |
+                               (uint32_t)clampi(r1 >> 21, 0, 255) << 16 | (uint32_t)clampi(b1 >> 21, 0, 255) << 24;
+            *(uint32_t*)(cout + (size_t)(cY0 + j) * job.dw + (size_t)(cX0 + i2) * 2) = v;
+        }
+    }
+}
+
+// ---- filter bank, host side: the specification's integer arithmetic (see the header of oracle/frontend_oracle.c for the
+//      same text as prose; the two are written independently and compared tap by tap in tests/test_gpu_frontend.py)
+int64_t floor_div64(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+    return q;
+}
+int64_t bicubic_weight(int64_t x) {          // x: |distance| / scale in 16.16; B = 0, C = 0.6, times 10 * 2^16
+    const int64_t one = 65536;
+    if (x < one) return ((14 * x * x * x) >> 32) - ((24 * x * x) >> 16) + 10 * one;
+    if (x < 2 * one) return -((6 * x * x * x) >> 32) + ((30 * x * x) >> 16) - 48 * x + 24 * one;
+    return 0;
+}
+struct HostBank {
+    int taps = 0;
+    std::vector<int32_t> left;
+    std::vector<int16_t> coef;
+};
+bool make_bank(int src, int dst, HostBank* b) {
+    const int64_t xinc = (((int64_t)src << 16) + dst / 2) / dst;
+    const int64_t scale = xinc > 65536 ? xinc : 65536;
+    const int64_t R = 2 * scale;
+    b->taps = (int)((2 * R + 65535) >> 16);
+    if (b->taps > 64) return false;
+    b->left.resize((size_t)dst);
+    b->coef.resize((size_t)dst * b->taps);
+    std::vector<int64_t> W((size_t)b->taps);
+    for (int i = 0; i < dst; i++) {
+        const int64_t c = (int64_t)i * xinc + ((xinc - 65536) >> 1);
+        const int64_t l = floor_div64(c - R, 65536) + 1;
+        int64_t sum = 0;
+        int best = 0;
+        for (int k = 0; k < b->taps; k++) {
+            int64_t d = ((l + k) << 16) - c;
+            if (d < 0) d = -d;
+            W[(size_t)k] = bicubic_weight(d * 65536 / scale);
+            sum += W[(size_t)k];
+            if (W[(size_t)k] > W[(size_t)best]) best = k;
+        }
+        int64_t got = 0;
+        for (int k = 0; k < b->taps; k++) {
+            const int64_t q = W[(size_t)k] * 16384 / sum;
+            b->coef[(size_t)i * b->taps + k] = (int16_t)q;
+            got += q;
+        }
+        b->coef[(size_t)i * b->taps + best] = (int16_t)(b->coef[(size_t)i * b->taps + best] + (16384 - got));
+        b->left[(size_t)i] = (int32_t)l;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct psxhip_scaler {
+    int device, fmt, sw, sh, full_range, dw, dh;
+    HostBank h[4];                 // lh, lv, ch, cv
+    int32_t* d_left[4] = {nullptr, nullptr, nullptr, nullptr};
+    int16_t* d_coef[4] = {nullptr, nullptr, nullptr, nullptr};
+    ScalerJob job;
+    size_t lds_bytes;
+    size_t src_bytes;              // bytes of one source picture
+};
+
+#define HIP_TRY(expr, code)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            psxhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (code);                                                                    \
+        }                                                                                     \
+    } while (0)
+
+extern "C" void psxhip_scaler_destroy(psxhip_scaler_t* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (int i = 0; i < 4; i++) {
+        if (s->d_left[i]) (void)hipFree(s->d_left[i]);
+        if (s->d_coef[i]) (void)hipFree(s->d_coef[i]);
+    }
+    delete s;
+}
+
+extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_format, int src_width, int src_height,
+                                    int src_full_range, int dst_width, int dst_height) {
+    if (!out) return PSXHIP_EINVAL;
+    *out = nullptr;
+    const bool yuv = src_format == PSXHIP_PIX_YUV420P;
+    if ((src_format != PSXHIP_PIX_RGB24 && !yuv) || src_width < 2 || src_height < 2 || src_width > 16384 || src_height > 16384 ||
+        dst_width < 16 || dst_height < 16 || (dst_width % 16) || (dst_height % 16) || dst_width > 1024 || dst_height > 1024 ||
+        (yuv && ((src_width | src_height) & 1))) {
+        psxhip_set_error("psxhip_scaler_create: bad geometry (%dx%d format %d -> %dx%d; the target must be a multiple of 16, YUV420P sources even)",
+                         src_width, src_height, src_format, dst_width, dst_height);
+        return PSXHIP_EINVAL;
+    }
+    int rc = psxhip_ensure_device(device);
+    if (rc) return rc;
+    psxhip_scaler* s = new (std::nothrow) psxhip_scaler;
+    if (!s) return PSXHIP_ENOMEM;
+    struct Guard { psxhip_scaler* p; ~Guard() { if (p) psxhip_scaler_destroy(p); } } guard{s};
+    s->device = device; s->fmt = src_format; s->sw = src_width; s->sh = src_height; s->full_range = src_full_range;
+    s->dw = dst_width; s->dh = dst_height;
+    const int csw = yuv ? src_width / 2 : src_width, csh = yuv ? src_height / 2 : src_height;
+    if (!make_bank(src_width, dst_width, &s->h[0]) || !make_bank(src_height, dst_height, &s->h[1]) ||
+        !make_bank(csw, dst_width / 2, &s->h[2]) || !make_bank(csh, dst_height / 2, &s->h[3])) {
+        psxhip_set_error("psxhip_scaler_create: shrinking by more than 16x is not supported");
+        return PSXHIP_EINVAL;
+    }
+    s->src_bytes = yuv ? (size_t)src_width * src_height * 3 / 2 : (size_t)src_width * src_height * 3;
+    ScalerJob& j = s->job;
+    memset(&j, 0, sizeof j);
+    j.sw = src_width; j.sh = src_height; j.dw = dst_width; j.dh = dst_height;
+    j.csw = csw; j.csh = csh;
+    j.limited = yuv && !src_full_range;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
+    // tile: the largest of these whose LDS working set leaves room for at least two workgroups per CU
+    const int shapes[4][2] = {{64, 16}, {32, 16}, {32, 8}, {16, 8}};
+    size_t need = 0;
+    bool ok = false;
+    for (int t = 0; t < 4 && !ok; t++) {
+        const int TW = shapes[t][0], TH = shapes[t][1];
+        // the largest source reach of any tile, from the tables
+        auto reach = [](const HostBank& b, int n, int tile, int* lo_of_first, int* span) {
+            int best = 0;
+            for (int a = 0; a < n; a += tile) {
+                const int e = (a + tile < n ? a + tile : n) - 1;
+                const int sp = b.left[(size_t)e] + b.taps - b.left[(size_t)a];
+                if (sp > best) best = sp;
+            }
+            (void)lo_of_first;
+            *span = best;
+        };
+        int lc, lr, cc, cr;
+        reach(s->h[0], dst_width, TW, nullptr, &lc);
+        reach(s->h[1], dst_height, TH, nullptr, &lr);
+        reach(s->h[2], dst_width / 2, TW / 2, nullptr, &cc);
+        reach(s->h[3], dst_height / 2, TH / 2, nullptr, &cr);
+        int reg_rows, reg_cols, creg_rows, creg_cols;
+        if (yuv) {
+            reg_rows = lr; reg_cols = lc; creg_rows = cr; creg_cols = cc;
+        } else {
+            // the union of the luma and the chroma reach over the same full-resolution picture: bounded by the larger span plus
+            // the offset between the two windows (at most the larger filter's half width); take the exact maximum over the tiles
+            reg_rows = 0; reg_cols = 0;
+            for (int a = 0; a < dst_width; a += TW) {
+                const int e = (a + TW < dst_width ? a + TW : dst_width) - 1;
+                const int lo = std::min(s->h[0].left[(size_t)a], s->h[2].left[(size_t)(a / 2)]);
+                const int hi = std::max(s->h[0].left[(size_t)e] + s->h[0].taps, s->h[2].left[(size_t)(e / 2)] + s->h[2].taps);
+                reg_cols = std::max(reg_cols, hi - lo);
+            }
+            for (int a = 0; a < dst_height; a += TH) {
+                const int e = (a + TH < dst_height ? a + TH : dst_height) - 1;
+                const int lo = std::min(s->h[1].left[(size_t)a], s->h[3].left[(size_t)(a / 2)]);
+                const int hi = std::max(s->h[1].left[(size_t)e] + s->h[1].taps, s->h[3].left[(size_t)(e / 2)] + s->h[3].taps);
+                reg_rows = std::max(reg_rows, hi - lo);
+            }
+            creg_rows = reg_rows; creg_cols = reg_cols;
+        }
+        const size_t plane = ((size_t)reg_rows * reg_cols + 15) & ~(size_t)15;
+        const size_t cplane = yuv ? (((size_t)creg_rows * creg_cols + 15) & ~(size_t)15) : plane;
+        const size_t crows_cap = yuv ? (size_t)creg_rows : (size_t)reg_rows;
+        need = plane + 2 * cplane + 2 * ((size_t)reg_rows * TW + 2 * crows_cap * (TW / 2)) +
+               2 * ((size_t)TW * s->h[0].taps + (size_t)TH * s->h[1].taps + (size_t)(TW / 2) * s->h[2].taps + (size_t)(TH / 2) * s->h[3].taps) + 4 +
+               4 * ((size_t)TW + TH + TW / 2 + TH / 2) + 16;
+        if (need * 2 <= (size_t)prop.maxSharedMemoryPerMultiProcessor || (t == 3 && need <= (size_t)prop.maxSharedMemoryPerMultiProcessor)) {
+            ok = true;
+            j.TW = TW; j.TH = TH;
+            j.reg_rows = reg_rows; j.reg_cols = reg_cols; j.creg_rows = creg_rows; j.creg_cols = creg_cols;
+        }
+    }
+    if (!ok) {
+        psxhip_set_error("psxhip_scaler_create: the filters' reach (%zu bytes of LDS per tile) does not fit a compute unit", need);
+        return PSXHIP_EINVAL;
+    }
+    s->lds_bytes = need;
+    j.tiles_x = (dst_width + j.TW - 1) / j.TW;
+    j.tiles_y = (dst_height + j.TH - 1) / j.TH;
+    for (int i = 0; i < 4; i++) {
+        HIP_TRY(hipMalloc((void**)&s->d_left[i], s->h[i].left.size() * sizeof(int32_t)), PSXHIP_ENOMEM);
+        HIP_TRY(hipMalloc((void**)&s->d_coef[i], s->h[i].coef.size() * sizeof(int16_t)), PSXHIP_ENOMEM);
+        HIP_TRY(hipMemcpy(s->d_left[i], s->h[i].left.data(), s->h[i].left.size() * sizeof(int32_t), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+        HIP_TRY(hipMemcpy(s->d_coef[i], s->h[i].coef.data(), s->h[i].coef.size() * sizeof(int16_t), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+    }
+    Bank* banks[4] = {&j.lh, &j.lv, &j.ch, &j.cv};
+    for (int i = 0; i < 4; i++) {
+        banks[i]->left = s->d_left[i];
+        banks[i]->coef = s->d_coef[i];
+        banks[i]->taps = s->h[i].taps;
+    }
+    if (yuv) HIP_TRY(hipFuncSetAttribute((const void*)scaler_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
+    else HIP_TRY(hipFuncSetAttribute((const void*)scaler_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
+    guard.p = nullptr;
+    *out = s;
+    return PSXHIP_OK;
+}
+
+extern "C" size_t psxhip_scaler_source_bytes(const psxhip_scaler_t* s) { return s ? s->src_bytes : 0; }
+
+extern "C" int psxhip_scaler_filter(const psxhip_scaler_t* s, int which, int* taps, int32_t* left, int16_t* coef, int cap) {
+    if (!s || which < 0 || which > 3) return PSXHIP_EINVAL;
+    const HostBank& b = s->h[which];
+    if (taps) *taps = b.taps;
+    const int n = (int)b.left.size();
+    if (left && coef) {
+        if (cap < n * b.taps) return PSXHIP_EINVAL;
+        memcpy(left, b.left.data(), (size_t)n * sizeof(int32_t));
+        memcpy(coef, b.coef.data(), (size_t)n * b.taps * sizeof(int16_t));
+    }
+    return n;
+}
+
+extern "C" int psxhip_scaler_convert_device(psxhip_scaler_t* s, const uint8_t* d_src, size_t src_stride, int n_frames,
+                                            uint8_t* d_frames, size_t frame_stride, void* stream) {
+    if (!s || !d_src || !d_frames || n_frames < 0) {
+        psxhip_set_error("psxhip_scaler_convert_device: NULL argument");
+        return PSXHIP_EINVAL;
+    }
+    if (n_frames == 0) return PSXHIP_OK;
+    if (src_stride < s->src_bytes || frame_stride < (size_t)s->dw * s->dh * 3 / 2 || (frame_stride & 3) || ((uintptr_t)d_frames & 3)) {
+        psxhip_set_error("psxhip_scaler_convert_device: strides too small, or the output not 4-byte aligned");
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(s->device), PSXHIP_EDEVICE);
+    ScalerJob j = s->job;
+    j.src = d_src; j.src_stride = src_stride; j.out = d_frames; j.frame_stride = frame_stride;
+    const int tiles = j.tiles_x * j.tiles_y;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {            // gridDim.y limit
+        const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+        j.src = d_src + (size_t)f0 * src_stride;
+        j.out = d_frames + (size_t)f0 * frame_stride;
+        if (s->fmt == PSXHIP_PIX_YUV420P)
+            hipLaunchKernelGGL(scaler_kernel<1>, dim3((unsigned)tiles, (unsigned)nf), dim3(256), s->lds_bytes, (hipStream_t)stream, j);
+        else
+            hipLaunchKernelGGL(scaler_kernel<0>, dim3((unsigned)tiles, (unsigned)nf), dim3(256), s->lds_bytes, (hipStream_t)stream, j);
+    }
+    HIP_TRY(hipGetLastError(), PSXHIP_EDEVICE);
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_scaler_convert_host(psxhip_scaler_t* s, const uint8_t* src, int n_frames, uint8_t* frames) {
+    if (!s || !src || !frames || n_frames < 0) return PSXHIP_EINVAL;
+    if (n_frames == 0) return PSXHIP_OK;
+    HIP_TRY(hipSetDevice(s->device), PSXHIP_EDEVICE);
+    const size_t fsz = (size_t)s->dw * s->dh * 3 / 2;
+    uint8_t *d_src = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_src, s->src_bytes * (size_t)n_frames), PSXHIP_ENOMEM);
+    if (hipMalloc((void**)&d_out, fsz * (size_t)n_frames) != hipSuccess) { (void)hipFree(d_src); return PSXHIP_ENOMEM; }
+    hipError_t e = hipMemcpy(d_src, src, s->src_bytes * (size_t)n_frames, hipMemcpyHostToDevice);
+    int rc = PSXHIP_OK;
+    if (e == hipSuccess) rc = psxhip_scaler_convert_device(s, d_src, s->src_bytes, n_frames, d_out, fsz, nullptr);
+    if (e == hipSuccess && rc == PSXHIP_OK) e = hipMemcpy(frames, d_out, fsz * (size_t)n_frames, hipMemcpyDeviceToHost);
+    (void)hipFree(d_src);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        psxhip_set_error("psxhip_scaler_convert_host: %s", hipGetErrorString(e));
+        return PSXHIP_EDEVICE;
+    }
+    return rc;
+}

@@ -102,6 +102,8 @@ def lib():
         L.orc_edc_crc32.restype = C.c_uint32
         L.orc_cdrom_init_sector.argtypes = [u8p, C.c_int, C.c_int]
         L.orc_cdrom_calculate_checksums.argtypes = [u8p, C.c_int]
+        L.orc_scaler_filter.argtypes = [C.c_int, C.c_int, intp, C.POINTER(C.c_int32), i16p, C.c_int]
+        L.orc_scaler_convert.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
         _lib = L
     return _lib
 
@@ -230,3 +232,27 @@ def ref_xa_encode(settings, samples, sample_count, lba=0, state=None):
     out = np.zeros(nsec * 2352 + 16, dtype=np.uint8)
     ln = R.psx_audio_xa_encode(rs, C.byref(st), ptr(samples, i16p), sample_count, lba, ptr(out, u8p))
     return out[:ln], st
+
+
+# ---------------------------------------------------------------- front-end helpers (oracle/frontend_oracle.c)
+PIX_RGB24, PIX_YUV420P = 0, 1
+
+
+def scaler_filter(src, dst):
+    """(taps, left (dst,), coef (dst, taps)) of the front-end's bicubic filter bank"""
+    left = np.zeros(dst, np.int32)
+    coef = np.zeros(dst * 64, np.int16)
+    taps = C.c_int()
+    rc = lib().orc_scaler_filter(src, dst, C.byref(taps), left.ctypes.data_as(C.POINTER(C.c_int32)), ptr(coef, i16p), coef.size)
+    assert rc == 0
+    return taps.value, left, coef[:dst * taps.value].reshape(dst, taps.value)
+
+
+def scaler_convert(fmt, src_w, src_h, full_range, dst_w, dst_h, pictures):
+    """pictures: (n, bytes per picture) uint8 -> (n, dst_w * dst_h * 3 / 2) NV21"""
+    pictures = np.ascontiguousarray(pictures, dtype=np.uint8)
+    out = np.zeros((pictures.shape[0], dst_w * dst_h * 3 // 2), np.uint8)
+    for i in range(pictures.shape[0]):
+        rc = lib().orc_scaler_convert(fmt, src_w, src_h, int(full_range), dst_w, dst_h, ptr(pictures[i], u8p), ptr(out[i], u8p))
+        assert rc == 0, rc
+    return out
