@@ -351,12 +351,17 @@ struct ChunkJob {
     psxhip_adpcm_state_t* unit_states;          // state after every unit
     psxhip_adpcm_state_t* start_used;           // [n_chunks] state each chunk was last encoded from
     uint8_t* units;
-    int* changed;                    // verify: set to 1 when any chunk had to be re-encoded
+    int* changed;                    // verify: set to 1 when any chunk had to be re-encoded (device memory, one word per pass)
+    const int* changed_before;       // verify: the previous pass's word, NULL for the first pass of a batch -- a pass whose
+                                     // predecessor changed nothing has nothing to do (the fixpoint was reached) and returns at once
 };
 
 template <bool VERIFY, int ROW>
 __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job) {
     constexpr int kRows = 64 / ROW;            // chains per wavefront: 4 or 5
+    // Verify passes are launched several at a time, back to back, without a host round trip in between (a synchronise + launch
+    // per pass was 40-50 us, as much as re-encoding 40 sound units); the passes after the one that changed nothing fall through here
+    if (VERIFY && job.changed_before && *job.changed_before == 0) return;
     const int lane = (int)(threadIdx.x & 63);
     const int row = row_of<ROW>(lane), col = col_of<ROW>(lane);
     const int chunk = (int)blockIdx.x * kRows + row;
@@ -707,7 +712,7 @@ struct psxhip_adpcm_session {
     bool speculated;
     hipStream_t stream;
     ChunkJob job;
-    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_cstates, d_lead, d_final, d_known;
+    DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_cstates, d_lead, d_final, d_known, d_flags;
 };
 
 #define TRY(expr)                                                                                   \
@@ -764,6 +769,7 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     if (e == hipSuccess) e = s->d_cstates.alloc(sizeof(psxhip_adpcm_state_t) * nc);
     if (e == hipSuccess) e = s->d_final.alloc(sizeof(psxhip_adpcm_state_t) * nc);
     if (e == hipSuccess) e = s->d_known.alloc(nc);
+    if (e == hipSuccess) e = s->d_flags.alloc(16 * sizeof(int));
     if (e == hipSuccess) e = s->d_cchain.alloc(sizeof(int32_t) * nk);
     if (e == hipSuccess) e = s->d_cfirst.alloc(sizeof(int32_t) * nk);
     if (e == hipSuccess) e = s->d_used.alloc(sizeof(psxhip_adpcm_state_t) * nk);
@@ -803,7 +809,8 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     job.unit_states = s->d_ustates.as<psxhip_adpcm_state_t>();
     job.start_used = s->d_used.as<psxhip_adpcm_state_t>();
     job.units = d_units;
-    job.changed = nullptr;      // set by session_run: the running thread's flag word
+    job.changed = nullptr;      // set by session_run, per pass
+    job.changed_before = nullptr;
     guard.p = nullptr;                   // ownership passes to the caller
     *out = s;
     return PSXHIP_OK;
@@ -836,41 +843,55 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
     else TRY(hipMemsetAsync(s->d_known.p, 1, (size_t)s->n_chains, st));
     int passes = 0;
     if (s->n_chunks) {
-        // "some chunk's start state changed" is a word of page-locked host memory the verify kernel raises and the host reads
-        // after the stream synchronise: no memset / copy per pass, nothing queued on a copy engine that may be busy with
-        // somebody else's frames.  One word per host thread (a run is synchronous).
-        static thread_local int* flag = nullptr;
-        if (!flag && hipHostMalloc((void**)&flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
-            flag = nullptr;
-            psxhip_set_error("adpcm_session_run: no page-locked memory for the verify flag");
+        // "some chunk's start state changed" is one word of device memory per pass.  Passes are launched in batches, back to
+        // back: pass i + 1 looks at pass i's word when it starts and returns at once if nothing changed, so the host reads the
+        // words once per batch -- no synchronise + launch round trip (40-50 us) per pass.  The words travel back through a
+        // page-locked buffer of the calling thread (a run is synchronous).
+        constexpr int kBatchMax = 16;
+        static thread_local int* h_flags = nullptr;
+        if (!h_flags && hipHostMalloc((void**)&h_flags, kBatchMax * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            h_flags = nullptr;
+            psxhip_set_error("adpcm_session_run: no page-locked memory for the verify flags");
             return PSXHIP_ENOMEM;
         }
-        s->job.changed = flag;
+        int* d_flags = s->d_flags.as<int>();
         // XA's 4 filters fill 12 of a row's lanes: 12-lane rows, five chunks per wavefront; SPU's 5 filters need 16-lane rows
         const bool narrow = s->job.filter_count == 4;
         const int per = narrow ? 5 : 4;
         const dim3 grid((unsigned)((s->n_chunks + per - 1) / per)), block(64);
         if (!s->speculated) {
+            s->job.changed = d_flags;
+            s->job.changed_before = nullptr;
             if (narrow) hipLaunchKernelGGL((adpcm_chunks_kernel<false, 12>), grid, block, 0, st, s->job);
             else hipLaunchKernelGGL((adpcm_chunks_kernel<false, 16>), grid, block, 0, st, s->job);
             TRY(hipGetLastError());
             s->speculated = true;
             if (any_change) *any_change = 1;
         }
-        for (;;) {
-            *(volatile int*)flag = 0;      // (no verify kernel is in flight here: the previous pass ended with a synchronise)
-            if (narrow) hipLaunchKernelGGL((adpcm_chunks_kernel<true, 12>), grid, block, 0, st, s->job);
-            else hipLaunchKernelGGL((adpcm_chunks_kernel<true, 16>), grid, block, 0, st, s->job);
-            TRY(hipGetLastError());
-            TRY(hipStreamSynchronize(st));
-            const int changed = *(volatile int*)flag;
-            passes++;
-            if (!changed) break;
-            if (any_change) *any_change = 1;
-            if (max_passes > 0 && passes >= max_passes) {
+        // first batch: most material is done after "one pass that repairs + one that finds nothing"
+        int batch = 3;
+        for (bool done = false; !done;) {
+            if (max_passes > 0 && passes + batch > max_passes) batch = max_passes - passes;
+            if (batch < 1) {
                 psxhip_set_error("adpcm_session_run: not converged after %d verify passes", passes);
                 return PSXHIP_EINVAL;
             }
+            TRY(hipMemsetAsync(d_flags, 0, kBatchMax * sizeof(int), st));
+            for (int i = 0; i < batch; i++) {
+                s->job.changed = d_flags + i;
+                s->job.changed_before = i ? d_flags + i - 1 : nullptr;
+                if (narrow) hipLaunchKernelGGL((adpcm_chunks_kernel<true, 12>), grid, block, 0, st, s->job);
+                else hipLaunchKernelGGL((adpcm_chunks_kernel<true, 16>), grid, block, 0, st, s->job);
+            }
+            TRY(hipGetLastError());
+            TRY(hipMemcpyAsync(h_flags, d_flags, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
+            TRY(hipStreamSynchronize(st));
+            for (int i = 0; i < batch && !done; i++) {
+                passes++;                      // this pass ran
+                if (h_flags[i]) { if (any_change) *any_change = 1; }
+                else done = true;              // it changed nothing: the fixpoint; the passes behind it returned at once
+            }
+            batch = batch * 2 < kBatchMax ? batch * 2 : kBatchMax;
         }
     }
     // chains without units keep their start state

@@ -9,10 +9,11 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-# kernel-trace: the bench's own command line (defaults: 20 steps x 16 launches), so that the kernel's average duration here
-# and bench.py's HIP-event mean are measurements of the same thing; PMC passes: a shorter run of the same workload
-full="python bench.py --no-cpu-baseline $*"
-cmd="python bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+# kernel-trace: the bench's own command line (defaults: 20 steps x 400 launches over 4 distinct batches), so that the kernel's
+# average duration here and bench.py's HIP-event mean are measurements of the same thing; PMC passes: a shorter run of the
+# same workload (counter collection serialises the kernels)
+full="python bench.py --no-cpu-baseline --no-secondary $*"
+cmd="python bench.py --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-secondary $*"
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- $full > $out/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o r -- $cmd > $out/write.log 2>&1
