@@ -686,7 +686,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         L.dcv[mbe * 6 + b0 + 1] = (int16_t)quant_dc(s1 - 64 * 128);
                     }
                 };
-                constexpr int kDcItems = 4;      // loads in flight per lane
+                constexpr int kDcItems = 8;      // loads in flight per lane
                 for (int item = wid; item < total_items; item += kDcItems * kWavesPerGroup) {
                     bool ch[kDcItems], ok[kDcItems];
                     int R[kDcItems], c[kDcItems];

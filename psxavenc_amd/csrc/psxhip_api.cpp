@@ -57,7 +57,7 @@ extern "C" void psxhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* psxhip_last_error(void) { return g_err; }
-extern "C" const char* psxhip_version(void) { return "psxav_hip 0.2 (gfx950, " PSXHIP_MDEC_KERNEL_REV ")"; }
+extern "C" const char* psxhip_version(void) { return "psxav_hip 0.3 (gfx950, " PSXHIP_MDEC_KERNEL_REV ")"; }
 
 extern "C" int psxhip_device_count(void) {
     int n = 0;

@@ -417,3 +417,18 @@ def test_strcd_config3_at_1000_frames():
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
     assert (p.quant_scale_sum, frames_encoded) == (qsum, 998)
+
+
+def test_c_multi_device_program_builds_runs_and_matches(tmp_path):
+    """examples/multi_encode.c: a plain-C host program (gcc only) that shards one batch over a device list with one call;
+    here over {0, 0, 0} with the host ticket queue -- the program itself compares against the single-device call"""
+    import os
+    import subprocess
+    root = O.ROOT
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "examples")], check=True)
+    for sched in ("static", "tickets"):
+        r = subprocess.run([os.path.join(root, "examples", "multi_encode"), "0,0,0", "1100", "320", "240", "8192", "0", sched],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the single-device call: yes" in r.stdout
+        assert r.stdout.count("worker") == 3
