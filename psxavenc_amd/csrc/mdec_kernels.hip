@@ -6,9 +6,10 @@
 //
 // Mapping (see DESIGN.md for the reasoning):
 //   * one workgroup owns one frame at a time (persistent grid, frames handed out by an atomic ticket);
-//   * one wavefront owns one macroblock at a time: 48 lanes run the row / column DCT butterflies of
-//     the six 8x8 blocks on packed int16 pairs (v_pk_add_i16 + v_dot2_i32_i16; 8x8 transposes staged in
-//     LDS), then lane k owns zig-zag position k of every block;
+//   * one wavefront owns one macroblock at a time: every lane hands the 8 pixels of its (block, row) to ONE
+//     v_mfma_i32_32x32x16_i8, which evaluates the row pass's eight exact integer forms for all 48 row vectors (pixels as one
+//     int8 digit, coefficients as two; fdct8_rows_mfma()); 48 lanes run the column pass on packed int16 pairs
+//     (v_pk_add_i16 + v_dot2_i32_i16; the 8x8 transposes are staged in LDS), then lane k owns zig-zag position k of every block;
 //   * quantisation is an exact integer rounding division done with one fp32 fma (proof at quant_mag());
 //     run lengths come from a 64-bit ballot + count-leading-zeros; code lengths and codes from
 //     (run, |level|) LUTs held in LDS; bit offsets from DPP prefix sums;
@@ -24,8 +25,10 @@
 //     tail included (the reference's memset, mdec.c:676).
 // There is no per-frame scratch in global memory: a frame's coefficients never leave the CU.
 //
-// MFMA is deliberately not used: the DCT is the bit-exact integer "islow" butterfly (see fdct8_pk()),
-// not a dense contraction, and everything after it is integer / bit manipulation.
+// The matrix pipe is used for exactly one thing: the DCT's row pass, as an exact int8-digit contraction (round 3; it frees
+// 15 of 262 VALU instructions per macroblock on the pipe that bounds the kernel).  The column pass (int16 inputs: two more
+// digits, three weight classes, a digit split of the row outputs) costs as many VALU instructions on the matrix pipe as off
+// it, and everything after the DCT is table look-ups and bit manipulation.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -198,6 +201,92 @@ __device__ __forceinline__ void fdct8_pk(uint32_t P0, uint32_t P1, uint32_t R0, 
     d[1] = dot2_k(D0, pk(C1_3, C1_2), dot2_k(D1, pk(C1_1, C1_0), rnd)) >> SH;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The ROW pass on the matrix pipe.  It is the same eight exact integer linear forms over the lane's 8 raw pixels -- an
+// 8 x 8 integer matrix times a pixel vector -- so v_mfma_i32_32x32x16_i8 evaluates it exactly in int32: the pixels are one
+// int8 digit (biased by -128: every form but out0 sums its coefficients to 0, and out0's 16 * 8 * 128 IS the level shift),
+// the <= 15-bit coefficients two balanced digits c = 256 h + l.  A (32 x 16) is block-diagonal over the two k-groups: rows
+// 0-7 / 8-15 = l / h digits acting on k 0-7, rows 16-23 / 24-31 the same on k 8-15; B (16 x 32): lane n holds the 8 pixels of
+// row vector n % 32 in k-group n / 32, i.e. every lane hands in its own vector -- 64 vectors per instruction, a macroblock's
+// 48 and 16 idle columns.  D: lane n < 32 receives outputs 0-3 of vectors n and 32 + n, lane 32 + n outputs 4-7 of the same
+// two, both digits of an output in one lane: out = (h << 8) + l, then the pass's rounding shift.  17 + 5 VALU instructions
+// per macroblock instead of 33, and the matrix pipe runs beside the other wavefronts' VALU work
+// (tools/microbench/dct_rowpass_mfma.hip: 0 of 512 outputs differ from the dot2 form; 41.5 against 66.3 ns per 64 vectors per
+// SIMD at 6 wavefronts per SIMD).  The COLUMN pass stays on v_dot2_i32_i16: its int16 inputs need two digits as well, three
+// weight classes to combine and a digit split of the row pass's outputs -- no instruction is saved.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+namespace rowm {
+constexpr int K_0_298 = 2446, K_0_390 = 3196, K_0_541 = 4433, K_0_765 = 6270, K_0_899 = 7373, K_1_175 = 9633, K_1_501 = 12299,
+              K_1_847 = 15137, K_1_961 = 16069, K_2_053 = 16819, K_2_562 = 20995, K_3_072 = 25172;
+constexpr int A = K_0_541 + K_0_765, B = K_0_541, C = K_0_541 - K_1_847;
+constexpr int C7_0 = K_0_298 - K_0_899 - K_1_961 + K_1_175, C7_1 = K_1_175, C7_2 = K_1_175 - K_1_961, C7_3 = K_1_175 - K_0_899;
+constexpr int C5_0 = K_1_175, C5_1 = K_2_053 - K_2_562 - K_0_390 + K_1_175, C5_2 = K_1_175 - K_2_562, C5_3 = K_1_175 - K_0_390;
+constexpr int C3_0 = K_1_175 - K_1_961, C3_1 = K_1_175 - K_2_562, C3_2 = K_3_072 - K_2_562 - K_1_961 + K_1_175, C3_3 = K_1_175;
+constexpr int C1_0 = K_1_175 - K_0_899, C1_1 = K_1_175 - K_0_390, C1_2 = K_1_175, C1_3 = K_1_501 - K_0_899 - K_0_390 + K_1_175;
+}  // namespace rowm
+// the row pass's forms over the pixels d0..d7 (with o3 = d0 - d7, o2 = d1 - d6, o1 = d2 - d5, o0 = d3 - d4): the same numbers as
+// fdct8_pk<false>'s dot products, written out per pixel
+__constant__ int16_t c_dct_row[8][8] = {
+    {16, 16, 16, 16, 16, 16, 16, 16},
+    {rowm::C1_3, rowm::C1_2, rowm::C1_1, rowm::C1_0, -rowm::C1_0, -rowm::C1_1, -rowm::C1_2, -rowm::C1_3},
+    {rowm::A, rowm::B, -rowm::B, -rowm::A, -rowm::A, -rowm::B, rowm::B, rowm::A},
+    {rowm::C3_3, rowm::C3_2, rowm::C3_1, rowm::C3_0, -rowm::C3_0, -rowm::C3_1, -rowm::C3_2, -rowm::C3_3},
+    {16, -16, -16, 16, 16, -16, -16, 16},
+    {rowm::C5_3, rowm::C5_2, rowm::C5_1, rowm::C5_0, -rowm::C5_0, -rowm::C5_1, -rowm::C5_2, -rowm::C5_3},
+    {rowm::B, rowm::C, -rowm::C, -rowm::B, -rowm::B, -rowm::C, rowm::C, rowm::B},
+    {rowm::C7_3, rowm::C7_2, rowm::C7_1, rowm::C7_0, -rowm::C7_0, -rowm::C7_1, -rowm::C7_2, -rowm::C7_3},
+};
+// lane l's 8 bytes of A: row l % 32 (k-group row / 16, digit (row / 8) & 1, output row & 7), k = 8 * (l / 32) .. + 7
+__device__ inline uint2 dct_row_a_operand(int lane) {
+    const int row = lane & 31, kg = lane >> 5;
+    const int grp = row >> 4, digit = (row >> 3) & 1, outp = row & 7;
+    uint32_t w[2] = {0u, 0u};
+    if (grp == kg)
+        for (int k = 0; k < 8; k++) {
+            const int c = (int)c_dct_row[outp][k];
+            const int lo = ((c + 128) & 255) - 128, hi = (c - lo) >> 8;
+            w[k >> 2] |= (uint32_t)((digit ? hi : lo) & 0xFF) << (8 * (k & 3));
+        }
+    return make_uint2(w[0], w[1]);
+}
+// b_lo / b_hi: the lane's 8 raw pixels (bytes).  o[0..3] / o[4..7]: this lane's four outputs (c = 4 * (lane >> 5) + r) of
+// row vector lane & 31 / of row vector 32 + (lane & 31), in the form store_row_outputs() takes
+__device__ __forceinline__ void fdct8_rows_mfma(uint32_t b_lo, uint32_t b_hi, uint2 a, int (&o)[8]) {
+    const long av = (long)(((unsigned long long)a.y << 32) | a.x);
+    const long bv = (long)(((unsigned long long)(b_hi ^ 0x80808080u) << 32) | (b_lo ^ 0x80808080u));
+    i32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; r++) zero[r] = 0;
+    const i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, bv, zero, 0, 0, 0);
+    // outputs 0 and 4 carry no fraction: x = (h << 8) + l.  The others are (x + 2^8) >> 9, an int16: left in the HIGH half of
+    // o[] as ((x + 2^8) << 7) = (h << 15) + ((l << 7) + 2^15) -- two shift-adds, and the store takes the high half
+    // (ds_write_b16_d16_hi), so the shift right costs nothing.  |x| < 2^24: no overflow.
+#pragma unroll
+    for (int v = 0; v < 2; v++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int l = acc[8 * v + r], h = acc[8 * v + 4 + r];
+            if (r == 0) {
+                o[4 * v + r] = (h << 8) + l;
+            } else {
+                // two v_lshl_add_u32.  The empty asm keeps `t` a value of its own (left alone the compiler shifts both digits and
+                // adds three ways); the instructions themselves stay the compiler's, because it is the compiler that has to see
+                // them read the matrix instruction's result registers and keep the wait states in front of them -- a hand-written
+                // v_lshl_add_u32 in an asm statement was scheduled straight behind the v_mfma.
+                uint32_t t = ((uint32_t)l << 7) + 0x8000u;
+                asm volatile("" : "+v"(t));
+                o[4 * v + r] = (int)(((uint32_t)h << 15) + t);
+            }
+        }
+}
+// the four outputs of one row vector -> the transpose tile (t: the vector's slot for output c = 4 * (lane >> 5), stride 8 per output)
+__device__ __forceinline__ void store_row_outputs(int16_t* t, const int* o) {
+    t[0] = (int16_t)o[0];
+#pragma unroll
+    for (int r = 1; r < 4; r++) t[r * 8] = (int16_t)(o[r] >> 16);
+}
+
 // A constant that is only stored (by one thread, once per frame) should be made where it is stored: hoisted out of the
 // frame loop it occupies a register for the whole kernel, and at 80 registers that means a scratch spill.
 __device__ __forceinline__ int in_loop(int x) {
@@ -232,7 +321,7 @@ struct Lds {
     uint8_t* dc_plen;       // [16]
     uint8_t* dc_prefix;     // [16]
     uint8_t* qzz;           // [64] quant matrix in scan order
-    uint4* tab_sel;         // [64] per lane: v_perm selectors of the pixel gather (PixelLane::sel)
+    uint4* tab_sel;         // [64] per lane: the two v_perm selectors of the pixel gather (PixelLane::sel), the lane's 8 bytes of the row pass's A matrix
     uint4* tab_pix;         // [64] per lane: pixel row offset, second-half offset, macroblock row shift, -
     uint8_t* tab_nat;       // [64] per lane k: where scan position k sits in a block of the coefficient tile (column * 8 + row)
     int16_t* tiles;         // per-wave DCT staging / code list
@@ -407,7 +496,7 @@ struct PixelLane {
     uint32_t lane_off;       // offset of this lane's pixel row inside macroblock (0, 0)
     uint32_t hi_off;         // chroma rows are 16 bytes long: second half
     uint32_t mb_row_shift;   // bytes per macroblock row for this lane's plane = 8 W << shift
-    uint32_t sel[4];         // v_perm selectors building (p0,p1) (p2,p3) (p7,p6) (p5,p4) as int16 pairs
+    uint32_t sel[2];         // v_perm selectors building the lane's 8 pixels as bytes p0..p3, p4..p7
 };
 __device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
     PixelLane p;
@@ -418,21 +507,17 @@ __device__ __forceinline__ PixelLane pixel_lane(int lane, int W, int H) {
     if (lane >= 48) p.lane_off = 0;                 // idle lanes read the frame's first bytes (unused)
     p.hi_off = is_chroma ? 8u : 0u;
     p.mb_row_shift = is_chroma ? 0u : 1u;
-    // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte pool {lo: 0..3, hi: 4..7}; 0x0C = 0x00.
-    // Pools (see load_pairs): A = {plo.x, plo.y}, B = {plo.y, phi.x}, C = {plo.y, phi.y}.
-    //   luma: the row's 8 pixels are plo.x, plo.y.  chroma: 16 bytes plo.x, plo.y, phi.x, phi.y with this
-    //   block's samples at even (Cr, blk 0) or odd (Cb, blk 1) bytes.
+    // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte pool {lo: 0..3, hi: 4..7}.
+    // Pools (see dct_mb): first four pixels from {plo.x, plo.y}, last four from {phi.x, phi.y}.
+    //   luma: the row's 8 pixels are plo.x, plo.y (phi = plo: the second fetch has offset 0).  chroma: 16 bytes plo.x, plo.y,
+    //   phi.x, phi.y with this block's samples at even (Cr, blk 0) or odd (Cb, blk 1) bytes.
     if (!is_chroma) {
-        p.sel[0] = 0x0C010C00u;    // (p0, p1) = A bytes 0, 1
-        p.sel[1] = 0x0C030C02u;    // (p2, p3) = A bytes 2, 3
-        p.sel[2] = 0x0C020C03u;    // (p7, p6) = C bytes 3, 2  (plo.y)
-        p.sel[3] = 0x0C000C01u;    // (p5, p4) = B bytes 1, 0  (plo.y)
+        p.sel[0] = 0x03020100u;    // p0..p3 = plo.x
+        p.sel[1] = 0x07060504u;    // p4..p7 = phi.y = plo.y
     } else {
         const uint32_t o = (uint32_t)blk;   // 0: even bytes, 1: odd bytes
-        p.sel[0] = 0x0C020C00u + o * 0x00010001u;   // (p0, p1) = plo.x bytes 0, 2 (+o)
-        p.sel[1] = 0x0C060C04u + o * 0x00010001u;   // (p2, p3) = plo.y bytes 0, 2 = A bytes 4, 6
-        p.sel[2] = 0x0C040C06u + o * 0x00010001u;   // (p7, p6) = phi.y bytes 2, 0 = C bytes 6, 4
-        p.sel[3] = 0x0C040C06u + o * 0x00010001u;   // (p5, p4) = phi.x bytes 2, 0 = B bytes 6, 4
+        p.sel[0] = 0x06040200u + o * 0x01010101u;
+        p.sel[1] = 0x06040200u + o * 0x01010101u;
     }
     return p;
 }
@@ -524,7 +609,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid < 64) {
             L.qzz[tid] = pro_qzz;
             const PixelLane p = pixel_lane(tid, W, H);
-            L.tab_sel[tid] = make_uint4(p.sel[0], p.sel[1], p.sel[2], p.sel[3]);
+            const uint2 am = dct_row_a_operand(tid);
+            L.tab_sel[tid] = make_uint4(p.sel[0], p.sel[1], am.x, am.y);
             L.tab_pix[tid] = make_uint4(p.lane_off, p.hi_off, p.mb_row_shift, 0u);
             const int raster = (int)pro_zagzig;
             L.tab_nat[tid] = (uint8_t)((raster & 7) * 8 + (raster >> 3));
@@ -810,17 +896,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
         auto dct_mb = [&](bool have_next, int next_fx, int next_fy) {
             const uint4 ts = L.tab_sel[lane];
-            const uint32_t P0 = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
-            const uint32_t P1 = __builtin_amdgcn_perm(plo.y, plo.x, ts.y);
-            const uint32_t R0 = __builtin_amdgcn_perm(phi.y, plo.y, ts.z);
-            const uint32_t R1 = __builtin_amdgcn_perm(phi.x, plo.y, ts.w);
-            if (have_next) fetch(next_fx, next_fy);
+            const uint32_t b_lo = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
+            const uint32_t b_hi = __builtin_amdgcn_perm(phi.y, phi.x, ts.y);
+            if (have_next) fetch(next_fx, next_fy);          // (issued behind the matrix instruction instead, the loads leave 2 % later)
             int d[8];
-            if (lane < 48) {
-                // -- row pass: lane = (block, row)
-                fdct8_pk<false>(P0, P1, R0, R1, d);
-#pragma unroll
-                for (int c = 0; c < 8; c++) tileT[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+            {
+                // -- row pass on the matrix pipe: every lane hands in its own row vector (lane = (block, row); lanes 48..63 idle
+                //    columns), and gets back four outputs of vector lane & 31 and four of vector 32 + (lane & 31)
+                fdct8_rows_mfma(b_lo, b_hi, make_uint2(ts.z, ts.w), d);
+                const int n = lane & 31;
+                int16_t* t0 = tileT + (n >> 3) * kTileStride + (n & 7) + (lane >> 5) * 32;      // output c = 4 * (lane >> 5) + r at c * 8
+                store_row_outputs(t0, d);
+                if (n < 16) store_row_outputs(t0 + 4 * kTileStride, d + 4);                      // vectors 32..47: blocks 4, 5
             }
             wave_sync();
             if (lane < 48) {
@@ -1588,14 +1675,19 @@ __global__ __launch_bounds__(64) void mdec_fdct_probe_kernel(const int16_t* in, 
     const int b = (int)blockIdx.x * 6 + blk;
     const bool live = lane < 48 && b < n_blocks;
     int d[8];
-    if (live) {
-        const int16_t* p = in + (size_t)b * 64 + r8 * 8;
-        uint32_t x[8];
+    {
+        // row pass: the lane's 8 raw samples 0..255 as bytes, through the matrix pipe like the frame kernel
+        uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            const int16_t* p = in + (size_t)b * 64 + r8 * 8;
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = (uint32_t)((int)p[i] + 128) & 0xFFFFu;      // raw sample 0..255
-        fdct8_pk<false>(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[7] | (x[6] << 16), x[5] | (x[4] << 16), d);
-#pragma unroll
-        for (int c = 0; c < 8; c++) tile[blk * kTileStride + c * 8 + r8] = (int16_t)d[c];
+            for (int i = 0; i < 8; i++) x[i] = (uint32_t)((int)p[i] + 128) & 0xFFu;
+        }
+        fdct8_rows_mfma(x[0] | x[1] << 8 | x[2] << 16 | x[3] << 24, x[4] | x[5] << 8 | x[6] << 16 | x[7] << 24, dct_row_a_operand(lane), d);
+        const int n = lane & 31;
+        int16_t* t0 = tile + (n >> 3) * kTileStride + (n & 7) + (lane >> 5) * 32;
+        store_row_outputs(t0, d);
+        if (n < 16) store_row_outputs(t0 + 4 * kTileStride, d + 4);
     }
     __syncthreads();
     if (live) {

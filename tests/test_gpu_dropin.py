@@ -432,3 +432,49 @@ def test_c_multi_device_program_builds_runs_and_matches(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the single-device call: yes" in r.stdout
         assert r.stdout.count("worker") == 3
+
+
+def test_str_mux_randomised_settings_vs_reference_loop():
+    """seeded fuzz over what encode_file_str's behaviour depends on: container flavour, codec, frame rate (incl. NTSC's
+    30000/1001), CD speed, audio layout (mono / stereo, 4 / 8 bit, 18900 / 37800 Hz), trailing audio, frame count and the amount
+    of audio (none, less than the video, more) -- whole stream against the reference's sector loop over the oracle"""
+    import str_reference_loop as R
+    from psxavenc_amd import strmux
+    rng = np.random.default_rng(20260929)
+    mux = strmux.StrMuxer((0,))
+    done = 0
+    for trial in range(40):
+        fmt = int(rng.choice([6, 7, 9]))
+        codec = int(rng.integers(0, 3))
+        w, h = int(rng.choice([48, 64, 96, 160])), int(rng.choice([32, 48, 64, 112]))
+        fps = [(15, 1), (10, 1), (25, 1), (30000, 1001), (12, 1), (24000, 1001)][int(rng.integers(0, 6))]
+        speed = int(rng.integers(1, 3))
+        channels = int(rng.integers(0, 3))
+        bits = int(rng.choice([4, 8]))
+        freq = int(rng.choice([18900, 37800]))
+        trailing = bool(rng.integers(0, 2))
+        n_frames = int(rng.integers(1, 40))
+        s = strmux.settings(fmt=fmt, codec=codec, width=w, height=h, fps_num=fps[0], fps_den=fps[1], cd_speed=speed, channels=channels,
+                            frequency=freq, bits=bits, trailing_audio=trailing)
+        try:
+            p0 = strmux.plan(s, n_frames)
+        except Exception:
+            continue                        # frame rate too high for this CD speed: the product refuses, nothing to compare
+        if p0.max_frame_size > 60000:
+            continue
+        sps = p0.audio_samples_per_sector
+        n_audio = 0 if not channels else int(rng.choice([0, sps // 3, sps, 3 * sps + 11, (p0.n_audio_sectors + 3) * sps]))
+        frames = O.synth_frames(w, h, n_frames, seed=100 + trial, amp=int(rng.integers(2, 10)))
+        pcm = np.zeros(n_audio * max(1, channels), np.int16)
+        for c in range(channels):
+            pcm[c::channels] = O.synth_pcm(trial, c, 0, n_audio, int(rng.integers(0, 3))) if n_audio else 0
+        got, p = mux.encode(s, frames, pcm)
+        want, qsum, frames_encoded = R.encode_file_str(fmt, codec, w, h, fps[0], fps[1], speed, frames, pcm, channels=channels, freq=freq,
+                                                       bits=bits, trailing_audio=trailing)
+        ctx = (trial, fmt, codec, w, h, fps, speed, channels, bits, freq, trailing, n_frames, n_audio)
+        assert got.shape == want.shape, ctx
+        assert np.array_equal(got, want), (ctx, np.nonzero((got != want).any(axis=1))[0][:5].tolist())
+        assert (p.quant_scale_sum, p.n_frames_encoded) == (qsum, frames_encoded), ctx
+        done += 1
+    assert done >= 25
+    mux.close()
