@@ -796,11 +796,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // a chain is an inclusive scan under composition.  Chunks of 64 elements are spread over all wavefronts:
             // (A) scan inside each chunk, keep the chunk's total; (B) scan the totals of each chain -> the value
             // entering every chunk; (C) scan again inside each chunk, apply, emit deltas.
+            // A lane takes kPerLane CONSECUTIVE elements of a chain (composed serially in registers), the DPP scan then runs over
+            // the 64 lane totals: a chunk is 64 * kPerLane elements and costs one DPP scan (~80 VALU) + ~12 per element, instead of
+            // one DPP scan per 64 elements (the chain scan was ~22 of a 640x480 macroblock's ~250 VALU instructions, twice over).
             {
-                const int cc = (nmb + 63) >> 6, cy = (4 * nmb + 63) >> 6, n_chunks = 2 * cc + cy;
+                constexpr int kPerLane = 8, kChunk = 64 * kPerLane;
+                const int cc = (nmb + kChunk - 1) / kChunk, cy = (4 * nmb + kChunk - 1) / kChunk, n_chunks = 2 * cc + cy;
                 auto chunk_of = [&](int q, int& chain, int& base, int& count) {
                     chain = q < cc ? 0 : (q < 2 * cc ? 1 : 2);
-                    base = (q - (chain == 0 ? 0 : (chain == 1 ? cc : 2 * cc))) << 6;
+                    base = (q - (chain == 0 ? 0 : (chain == 1 ? cc : 2 * cc))) * kChunk;
                     count = chain == 2 ? 4 * nmb : nmb;
                 };
                 auto element = [&](int chain, int i, bool live, int& idx) -> StepFn {
@@ -814,14 +818,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const int rq = ((a + 2) >> 2) << 2;
                         f.thr = 0; f.lo = f.hi = dc < 0 ? -rq : rq;
                     }
-                    if (!live) { f.thr = -100000; f.lo = f.hi = 0; }   // dead lanes sit after all live ones, never feed them
+                    if (!live) { f.thr = -100000; f.lo = f.hi = 0; }   // dead elements sit after all live ones, never feed them
+                    return f;
+                };
+                // this lane's elements of chunk (chain, base) composed in order
+                auto lane_total = [&](int chain, int base, int count) -> StepFn {
+                    const int i0 = base + lane * kPerLane;
+                    int idx;
+                    StepFn f = element(chain, i0, i0 < count, idx);
+#pragma unroll
+                    for (int j = 1; j < kPerLane; j++) f = compose(f, element(chain, i0 + j, i0 + j < count, idx));
                     return f;
                 };
                 // (A)
                 for (int q = wid; q < n_chunks; q += kWavesPerGroup) {
-                    int chain, base, count, idx;
+                    int chain, base, count;
                     chunk_of(q, chain, base, count);
-                    StepFn f = element(chain, base + lane, base + lane < count, idx);
+                    StepFn f = lane_total(chain, base, count);
                     scan_stepfn(f, lane);
                     if (lane == 63) { L.dc_fn[4 * q + 0] = f.thr; L.dc_fn[4 * q + 1] = f.lo; L.dc_fn[4 * q + 2] = f.hi; }
                 }
@@ -843,28 +856,36 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                 }
                 group_sync(1);
-                // (C)
+                // (C) the value entering each lane's run, then the run itself, element by element
                 int bits = 0;
                 for (int q = wid; q < n_chunks; q += kWavesPerGroup) {
-                    int chain, base, count, idx;
+                    int chain, base, count;
                     chunk_of(q, chain, base, count);
-                    const bool live = base + lane < count;
-                    StepFn f = element(chain, base + lane, live, idx);
+                    StepFn f = lane_total(chain, base, count);
                     scan_stepfn(f, lane);
                     const int cin = L.dc_fn[4 * q + 3];
-                    const int cur = cin < f.thr ? f.lo : f.hi;               // last value after this element
-                    const int prev = __builtin_amdgcn_update_dpp(cin, cur, 0x138, 0xF, 0xF, false);
-                    int delta = (cur - prev) >> 2;                             // exact: both multiples of 4
-                    if (CODEC == 2) {                                          // v3dc wrap (mdec.c:469-474)
-                        if (delta < -0x80) delta += 0x100;
-                        else if (delta > 0x80) delta -= 0x100;
-                    }
-                    int dlen;
-                    uint32_t dcode;
-                    dc_code<CODEC>(delta, chain == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
-                    if (live) {
-                        L.dcv[idx] = (int16_t)delta;
-                        bits += dlen;
+                    const int after = cin < f.thr ? f.lo : f.hi;              // last value after this lane's run
+                    int prev = __builtin_amdgcn_update_dpp(cin, after, 0x138, 0xF, 0xF, false);      // ... entering it
+                    const int i0 = base + lane * kPerLane;
+#pragma unroll
+                    for (int j = 0; j < kPerLane; j++) {
+                        int idx;
+                        const bool live = i0 + j < count;
+                        const StepFn e = element(chain, i0 + j, live, idx);
+                        const int cur = prev < e.thr ? e.lo : e.hi;
+                        int delta = (cur - prev) >> 2;                         // exact: both multiples of 4
+                        if (CODEC == 2) {                                      // v3dc wrap (mdec.c:469-474)
+                            if (delta < -0x80) delta += 0x100;
+                            else if (delta > 0x80) delta -= 0x100;
+                        }
+                        int dlen;
+                        uint32_t dcode;
+                        dc_code<CODEC>(delta, chain == 2, L.dc_plen, L.dc_prefix, dlen, dcode);
+                        if (live) {
+                            L.dcv[idx] = (int16_t)delta;
+                            bits += dlen;
+                        }
+                        prev = cur;
                     }
                 }
                 bits = wave::reduce_add(bits);
