@@ -37,7 +37,9 @@ namespace {
 struct Bank {                 // one separable filter bank on the device
     const int32_t* left;      // [n]
     const int16_t* coef;      // [n * taps]
-    int taps;
+    const uint32_t* digits;   // [n * 2 * taps4] horizontal banks: the taps as two balanced int8 digits (c = 256 h + l), four taps
+                              //                 to a dword, zero-padded to taps4 dwords: first the l dwords, then the h dwords
+    int taps, taps4;
 };
 
 struct ScalerJob {
@@ -57,11 +59,32 @@ struct ScalerJob {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// The tap loops below carry `#pragma clang loop vectorize(disable) interleave(disable)`: hipcc 7.2 (LLVM 22git) versions the
-// vertical pass's loop for a unit row pitch, vectorises it, and the version it then runs with taps = 4 returned saturated
-// values for two of a lane's four outputs on the last three rows of every tile (enlarging 200x150 -> 320x240; found by
-// tests/test_gpu_frontend.py).  The loops are four to a few dozen trips of LDS reads and integer multiply-adds: there is
-// nothing for a vectoriser to win.
+// out8(): (acc >> 21) clamped to 0..255.  The value passes through an empty asm statement on purpose: hipcc 7.2 (LLVM 22git)
+// fuses "shift right, saturate to u8, pack two" into gfx950's v_ashr_pk_u8_i32 and then ORs the other two bytes of the dword
+// into the same register -- but the instruction leaves the destination's upper 16 bits as they were (the old accumulator), so
+// bytes 2 and 3 of every packed store came out as (right value | leftover bits).  Found by tests/test_gpu_frontend.py (first
+// on an enlarging geometry where only three rows per tile hit it, then on all rows once register allocation shifted).  No other
+// kernel of the library contains the instruction.
+__device__ __forceinline__ uint32_t out8(int acc) {
+    int v = acc >> 21;
+    asm volatile("" : "+v"(v));
+    return (uint32_t)clampi(v, 0, 255);
+}
+
+// (q, r) = divmod(start + k * step, d) for k = 0, 1, 2, ...: one division when the walk starts, a compare per step after that
+// (every loop of the kernel walks item = tid, tid + 256, ... over a rows x columns grid whose width is a run-time value;
+// a division per item cost more than the item's own work)
+struct DivWalk {
+    int q, r, dq, dr, d;
+    __device__ __forceinline__ DivWalk(int start, int step, int d_) : d(d_) {
+        q = start / d_; r = start - q * d_;
+        dq = step / d_; dr = step - dq * d_;
+    }
+    __device__ __forceinline__ void next() {
+        q += dq; r += dr;
+        if (r >= d) { r -= d; q++; }
+    }
+};
 
 template <int FMT>      // 0 = RGB24, 1 = YUV420P
 __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
@@ -82,24 +105,24 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     const int cya = job.cv.left[cY0], cyb = job.cv.left[cY0 + chh - 1] + job.cv.taps;
 
     // ---- LDS: three byte planes, the two intermediates, the tile's taps
-    const int plane_bytes = (job.reg_rows * job.reg_cols + 15) & ~15;
-    const int cplane_bytes = FMT == 0 ? plane_bytes : ((job.creg_rows * job.creg_cols + 15) & ~15);
+    const int plane_bytes = (job.reg_rows * job.reg_cols + 8 + 15) & ~15;
+    const int cplane_bytes = FMT == 0 ? plane_bytes : ((job.creg_rows * job.creg_cols + 8 + 15) & ~15);
     uint8_t* p0 = (uint8_t*)smem;
     uint8_t* p1 = p0 + plane_bytes;
     uint8_t* p2 = p1 + cplane_bytes;
     int16_t* tmpL = (int16_t*)(p2 + cplane_bytes);                               // [reg_rows][TW]
     int16_t* tmpC = tmpL + (size_t)job.reg_rows * TW;                             // [2][crows][CW]
     const int crows_cap = FMT == 0 ? job.reg_rows : job.creg_rows;
-    int16_t* f_lh = tmpC + (size_t)2 * crows_cap * CW;                            // [TW][taps]
-    int16_t* f_lv = f_lh + TW * job.lh.taps;
-    int16_t* f_ch = f_lv + TH * job.lv.taps;
-    int16_t* f_cv = f_ch + CW * job.ch.taps;
+    uint32_t* g_lh = (uint32_t*)(tmpC + (size_t)2 * crows_cap * CW);             // [TW][2 * taps4] digit dwords (l.., h..)
+    uint32_t* g_ch = g_lh + TW * 2 * job.lh.taps4;                                // [CW][2 * taps4]
+    int16_t* f_lv = (int16_t*)(g_ch + CW * 2 * job.ch.taps4);                     // [TH][taps]
+    int16_t* f_cv = f_lv + TH * job.lv.taps;
     int32_t* l_all = (int32_t*)(((uintptr_t)(f_cv + CH * job.cv.taps) + 3) & ~(uintptr_t)3);    // lefts: [TW] [TH] [CW] [CH]
     int32_t *l_lh = l_all, *l_lv = l_lh + TW, *l_ch = l_lv + TH, *l_cv = l_ch + CW;
 
-    for (int i = tid; i < tw * job.lh.taps; i += 256) f_lh[i] = job.lh.coef[(size_t)X0 * job.lh.taps + i];
+    for (int i = tid; i < tw * 2 * job.lh.taps4; i += 256) g_lh[i] = job.lh.digits[(size_t)X0 * 2 * job.lh.taps4 + i];
+    for (int i = tid; i < cw * 2 * job.ch.taps4; i += 256) g_ch[i] = job.ch.digits[(size_t)cX0 * 2 * job.ch.taps4 + i];
     for (int i = tid; i < th * job.lv.taps; i += 256) f_lv[i] = job.lv.coef[(size_t)Y0 * job.lv.taps + i];
-    for (int i = tid; i < cw * job.ch.taps; i += 256) f_ch[i] = job.ch.coef[(size_t)cX0 * job.ch.taps + i];
     for (int i = tid; i < chh * job.cv.taps; i += 256) f_cv[i] = job.cv.coef[(size_t)cY0 * job.cv.taps + i];
     if (tid < tw) l_lh[tid] = job.lh.left[X0 + tid];
     if (tid < th) l_lv[tid] = job.lv.left[Y0 + tid];
@@ -110,63 +133,150 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     int ya, yb, xa, xb;          // the region of plane 0 (and, RGB, of all three)
     int rcols, crcols;           // row pitch of the staged planes
     if (FMT == 0) {
-        ya = min(lya, cya); yb = max(lyb, cyb); xa = min(lxa, cxa); xb = max(lxb, cxb);
+        // the region starts and ends on multiples of four pixels: a lane converts four pixels = three dwords of the picture
+        // (12 bytes, aligned because a row is 3 * sw bytes and sw a multiple of 4) into one dword of each LDS plane
+        ya = min(lya, cya); yb = max(lyb, cyb);
+        xa = min(lxa, cxa) & ~3; xb = (max(lxb, cxb) + 3) & ~3;
         rcols = xb - xa;
         crcols = rcols;
-        const int rows = yb - ya;
-        // lane = one pixel; consecutive lanes read consecutive 3-byte pixels of a row
-        for (int item = tid; item < rows * rcols; item += 256) {
-            const int r = item / rcols, c = item - r * rcols;
-            const int sy = clampi(ya + r, 0, job.sh - 1), sx = clampi(xa + c, 0, job.sw - 1);
-            const uint8_t* px = src + ((size_t)sy * job.sw + sx) * 3;
-            const int R = px[0], G = px[1], B = px[2];
-            p0[item] = (uint8_t)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
-            p1[item] = (uint8_t)clampi(((-11059 * R - 21709 * G + 32768 * B + 32768) >> 16) + 128, 0, 255);     // Cb
-            p2[item] = (uint8_t)clampi(((32768 * R - 27439 * G - 5329 * B + 32768) >> 16) + 128, 0, 255);       // Cr
+        const int rows = yb - ya, groups = rcols >> 2;
+        const bool aligned = (job.sw & 3) == 0 && (((uintptr_t)src) & 3) == 0;
+        auto convert = [](int R, int G, int B, uint32_t& y, uint32_t& cb, uint32_t& cr) {
+            y = (uint32_t)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
+            cb = (uint32_t)clampi(((-11059 * R - 21709 * G + 32768 * B + 32768) >> 16) + 128, 0, 255);
+            cr = (uint32_t)clampi(((32768 * R - 27439 * G - 5329 * B + 32768) >> 16) + 128, 0, 255);
+        };
+        // kU groups per trip, all their loads issued before the first conversion: a lane that loads, converts and stores one
+        // group at a time spends a memory round trip per group (the first version: 27 of them per tile, 55 % of the kernel's
+        // wave-cycles waiting)
+        constexpr int kU = 4;
+        const int n_items = rows * groups;
+        DivWalk at(tid, 256, groups);
+        for (int base = tid; base < n_items; base += 256 * kU) {
+            uint32_t d[kU][3];
+            bool fast[kU];
+            int sy[kU], x0[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int item = base + u * 256;
+                const int r = at.q, g = at.r;
+                at.next();
+                sy[u] = clampi(ya + r, 0, job.sh - 1);
+                x0[u] = xa + 4 * g;
+                fast[u] = item < n_items && aligned && x0[u] >= 0 && x0[u] + 3 < job.sw;
+                d[u][0] = d[u][1] = d[u][2] = 0u;
+                if (fast[u]) {
+                    const uint32_t* q = (const uint32_t*)(src + ((size_t)sy[u] * job.sw + x0[u]) * 3);
+                    d[u][0] = q[0]; d[u][1] = q[1]; d[u][2] = q[2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int item = base + u * 256;
+                if (item >= n_items) continue;
+                uint32_t Y = 0, CB = 0, CR = 0;
+                if (fast[u]) {
+                    const uint32_t d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
+                    uint32_t y, cb, cr;
+                    convert((int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), y, cb, cr);
+                    Y = y; CB = cb; CR = cr;
+                    convert((int)(d0 >> 24), (int)(d1 & 255), (int)((d1 >> 8) & 255), y, cb, cr);
+                    Y |= y << 8; CB |= cb << 8; CR |= cr << 8;
+                    convert((int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)(d2 & 255), y, cb, cr);
+                    Y |= y << 16; CB |= cb << 16; CR |= cr << 16;
+                    convert((int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255), (int)(d2 >> 24), y, cb, cr);
+                    Y |= y << 24; CB |= cb << 24; CR |= cr << 24;
+                } else {                              // the picture's edges (clamped coordinates), or an unaligned picture
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint8_t* px = src + ((size_t)sy[u] * job.sw + clampi(x0[u] + k, 0, job.sw - 1)) * 3;
+                        uint32_t y, cb, cr;
+                        convert(px[0], px[1], px[2], y, cb, cr);
+                        Y |= y << (8 * k); CB |= cb << (8 * k); CR |= cr << (8 * k);
+                    }
+                }
+                ((uint32_t*)p0)[item] = Y;            // item = r * groups + g = dword index (rcols = 4 * groups)
+                ((uint32_t*)p1)[item] = CB;
+                ((uint32_t*)p2)[item] = CR;
+            }
         }
     } else {
-        ya = lya; yb = lyb; xa = lxa; xb = lxb;
+        // every plane's region starts and ends on multiples of four samples: a lane moves whole dwords
+        ya = lya; yb = lyb; xa = lxa & ~3; xb = (lxb + 3) & ~3;
         rcols = xb - xa;
-        crcols = cxb - cxa;
+        const int cxa4 = cxa & ~3, cxb4 = (cxb + 3) & ~3;
+        crcols = cxb4 - cxa4;
         const uint8_t* Y = src;
         const uint8_t* U = src + (size_t)job.sw * job.sh;
         const uint8_t* V = U + (size_t)job.csw * job.csh;
-        for (int item = tid; item < (yb - ya) * rcols; item += 256) {
-            const int r = item / rcols, c = item - r * rcols;
-            p0[item] = Y[(size_t)clampi(ya + r, 0, job.sh - 1) * job.sw + clampi(xa + c, 0, job.sw - 1)];
-        }
-        for (int item = tid; item < (cyb - cya) * crcols; item += 256) {
-            const int r = item / crcols, c = item - r * crcols;
-            const size_t o = (size_t)clampi(cya + r, 0, job.csh - 1) * job.csw + clampi(cxa + c, 0, job.csw - 1);
-            p1[item] = U[o];      // Cb
-            p2[item] = V[o];      // Cr
-        }
+        auto stage = [&](uint8_t* dst, const uint8_t* plane, int pw, int ph, int y0, int rows, int x0, int cols) {
+            const int groups = cols >> 2, n_items = rows * groups;
+            const bool aligned = (pw & 3) == 0 && (((uintptr_t)plane) & 3) == 0;
+            constexpr int kU = 8;
+            DivWalk at(tid, 256, groups);
+            for (int base = tid; base < n_items; base += 256 * kU) {
+                uint32_t v[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const int item = base + u * 256;
+                    const int r = at.q, g = at.r;
+                    at.next();
+                    const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
+                    v[u] = 0u;
+                    if (item < n_items) {
+                        if (aligned && x >= 0 && x + 3 < pw) {
+                            v[u] = *(const uint32_t*)(plane + (size_t)sy * pw + x);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[(size_t)sy * pw + clampi(x + k, 0, pw - 1)] << (8 * k);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kU; u++)
+                    if (base + u * 256 < n_items) ((uint32_t*)dst)[base + u * 256] = v[u];
+            }
+        };
+        stage(p0, Y, job.sw, job.sh, ya, yb - ya, xa, rcols);
+        stage(p1, U, job.csw, job.csh, cya, cyb - cya, cxa4, crcols);      // Cb
+        stage(p2, V, job.csw, job.csh, cya, cyb - cya, cxa4, crcols);      // Cr
     }
     __syncthreads();
 
-    // ---- horizontal pass, LDS -> LDS: 15-bit intermediates (+ the range expansion of limited-range input)
+    // ---- horizontal pass, LDS -> LDS: 15-bit intermediates (+ the range expansion of limited-range input).  Four taps at a
+    //      time: the window's bytes are fetched as aligned dwords and shifted into place (v_alignbit), biased to int8 (xor 0x80),
+    //      and multiplied by the taps' two int8 digits with v_dot4_i32_i8:
+    //      sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).  Exact.
+    auto hpass = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int taps4) -> int {
+        const uint32_t at = (uint32_t)(row * pitch + col);                  // byte offset of the window in the plane
+        const uint32_t* w = (const uint32_t*)(plane + (at & ~3u));
+        const uint32_t sh = (at & 3u) * 8u;
+        int acc_l = 0, acc_h = 0;
+        uint32_t cur = w[0];
+        for (int q = 0; q < taps4; q++) {
+            const uint32_t nxt = w[q + 1];
+            const uint32_t sv = __builtin_amdgcn_alignbit(nxt, cur, sh) ^ 0x80808080u;
+            acc_l = __builtin_amdgcn_sdot4((int)g[q], (int)sv, acc_l, false);
+            acc_h = __builtin_amdgcn_sdot4((int)g[taps4 + q], (int)sv, acc_h, false);
+            cur = nxt;
+        }
+        return (acc_h << 8) + acc_l + (128 << 14);
+    };
     {
-        const int rows = lyb - lya, r_off = lya - ya, c_off = -xa, taps = job.lh.taps;
-        for (int item = tid; item < rows * tw; item += 256) {
-            const int r = item / tw, i = item - r * tw;
-            const uint8_t* row = p0 + (size_t)(r + r_off) * rcols + (l_lh[i] + c_off);
-            const int16_t* f = f_lh + i * taps;
-            int acc = 0;
-#pragma clang loop vectorize(disable) interleave(disable)
-            for (int k = 0; k < taps; k++) acc += (int)f[k] * (int)row[k];
+        const int rows = lyb - lya, r_off = lya - ya, c_off = -xa, taps4 = job.lh.taps4;
+        DivWalk la(tid, 256, tw);
+        for (int item = tid; item < rows * tw; item += 256, la.next()) {
+            const int r = la.q, i = la.r;
+            const int acc = hpass(p0, rcols, r + r_off, l_lh[i] + c_off, g_lh + i * 2 * taps4, taps4);
             int t = clampi(acc >> 7, 0, 32767);
             if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
             tmpL[r * TW + i] = (int16_t)t;
         }
-        const int crows = cyb - cya, cr_off = FMT == 0 ? cya - ya : 0, cc_off = FMT == 0 ? -xa : -cxa, ctaps = job.ch.taps;
-        for (int item = tid; item < 2 * crows * cw; item += 256) {
-            const int comp = item / (crows * cw), rem = item - comp * crows * cw;
-            const int r = rem / cw, i = rem - r * cw;
-            const uint8_t* row = (comp ? p1 : p2) + (size_t)(r + cr_off) * crcols + (l_ch[i] + cc_off);      // comp 0 = Cr, 1 = Cb
-            const int16_t* f = f_ch + i * ctaps;
-            int acc = 0;
-#pragma clang loop vectorize(disable) interleave(disable)
-            for (int k = 0; k < ctaps; k++) acc += (int)f[k] * (int)row[k];
+        const int crows = cyb - cya, cr_off = FMT == 0 ? cya - ya : 0, cc_off = FMT == 0 ? -xa : -(cxa & ~3), ctaps4 = job.ch.taps4;
+        DivWalk ca(tid, 256, cw);
+        for (int item = tid; item < 2 * crows * cw; item += 256, ca.next()) {
+            const int comp = ca.q >= crows ? 1 : 0, r = ca.q - comp * crows, i = ca.r;      // rows 0..crows-1: Cr, then Cb
+            const int acc = hpass(comp ? p1 : p2, crcols, r + cr_off, l_ch[i] + cc_off, g_ch + i * 2 * ctaps4, ctaps4);      // comp 0 = Cr, 1 = Cb
             int t = clampi(acc >> 7, 0, 32767);
             if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
             tmpC[((size_t)comp * crows_cap + r) * CW + i] = (int16_t)t;
@@ -177,38 +287,36 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     // ---- vertical pass, LDS -> registers -> HBM: a lane makes four adjacent luma bytes / two adjacent Cr,Cb pairs
     {
         const int taps = job.lv.taps, q = tw >> 2;
-        for (int item = tid; item < th * q; item += 256) {
-            const int j = item / q, i4 = (item - j * q) * 4;
+        DivWalk va(tid, 256, q);
+        for (int item = tid; item < th * q; item += 256, va.next()) {
+            const int j = va.q, i4 = va.r * 4;
             const int16_t* f = f_lv + j * taps;
             const int16_t* col = tmpL + (size_t)(l_lv[j] - lya) * TW + i4;
             int a0 = 1 << 20, a1 = 1 << 20, a2 = 1 << 20, a3 = 1 << 20;
-#pragma clang loop vectorize(disable) interleave(disable)
             for (int k = 0; k < taps; k++) {
                 const int c = (int)f[k];
                 const int16_t* t = col + k * TW;
                 a0 += c * (int)t[0]; a1 += c * (int)t[1]; a2 += c * (int)t[2]; a3 += c * (int)t[3];
             }
-            const uint32_t v = (uint32_t)clampi(a0 >> 21, 0, 255) | (uint32_t)clampi(a1 >> 21, 0, 255) << 8 |
-                               (uint32_t)clampi(a2 >> 21, 0, 255) << 16 | (uint32_t)clampi(a3 >> 21, 0, 255) << 24;
+            const uint32_t v = out8(a0) | out8(a1) << 8 | out8(a2) << 16 | out8(a3) << 24;
             *(uint32_t*)(out + (size_t)(Y0 + j) * job.dw + X0 + i4) = v;
         }
         const int ctaps = job.cv.taps, cq = cw >> 1;
         uint8_t* cout = out + (size_t)job.dw * job.dh;
-        for (int item = tid; item < chh * cq; item += 256) {
-            const int j = item / cq, i2 = (item - j * cq) * 2;
+        DivWalk vc(tid, 256, cq);
+        for (int item = tid; item < chh * cq; item += 256, vc.next()) {
+            const int j = vc.q, i2 = vc.r * 2;
             const int16_t* f = f_cv + j * ctaps;
             const int16_t* cr = tmpC + (size_t)(l_cv[j] - cya) * CW + i2;
             const int16_t* cb = cr + (size_t)crows_cap * CW;
             int r0 = 1 << 20, r1 = 1 << 20, b0 = 1 << 20, b1 = 1 << 20;
-#pragma clang loop vectorize(disable) interleave(disable)
             for (int k = 0; k < ctaps; k++) {
                 const int c = (int)f[k];
                 r0 += c * (int)cr[k * CW]; r1 += c * (int)cr[k * CW + 1];
                 b0 += c * (int)cb[k * CW]; b1 += c * (int)cb[k * CW + 1];
             }
             // NV21: Cr at even bytes, Cb at odd (mdec.c:627-628)
-            const uint32_t v = (uint32_t)clampi(r0 >> 21, 0, 255) | (uint32_t)clampi(b0 >> 21, 0, 255) << 8 |
-                               (uint32_t)clampi(r1 >> 21, 0, 255) << 16 | (uint32_t)clampi(b1 >> 21, 0, 255) << 24;
+            const uint32_t v = out8(r0) | out8(b0) << 8 | out8(r1) << 16 | out8(b1) << 24;
             *(uint32_t*)(cout + (size_t)(cY0 + j) * job.dw + (size_t)(cX0 + i2) * 2) = v;
         }
     }
@@ -228,9 +336,10 @@ int64_t bicubic_weight(int64_t x) {          // x: |distance| / scale in 16.16; 
     return 0;
 }
 struct HostBank {
-    int taps = 0;
+    int taps = 0, taps4 = 0;
     std::vector<int32_t> left;
     std::vector<int16_t> coef;
+    std::vector<uint32_t> digits;       // see Bank::digits
 };
 bool make_bank(int src, int dst, HostBank* b) {
     const int64_t xinc = (((int64_t)src << 16) + dst / 2) / dst;
@@ -262,6 +371,17 @@ bool make_bank(int src, int dst, HostBank* b) {
         b->coef[(size_t)i * b->taps + best] = (int16_t)(b->coef[(size_t)i * b->taps + best] + (16384 - got));
         b->left[(size_t)i] = (int32_t)l;
     }
+    // the taps as two balanced int8 digits, four to a dword (the horizontal pass's v_dot4_i32_i8 operands)
+    b->taps4 = (b->taps + 3) / 4;
+    b->digits.assign((size_t)dst * 2 * b->taps4, 0u);
+    for (int i = 0; i < dst; i++)
+        for (int k = 0; k < b->taps; k++) {
+            const int c = b->coef[(size_t)i * b->taps + k];
+            const int lo = ((c + 128) & 255) - 128, hi = (c - lo) >> 8;
+            if (hi < -128 || hi > 127) return false;
+            b->digits[((size_t)i * 2 + 0) * b->taps4 + k / 4] |= (uint32_t)(lo & 0xFF) << (8 * (k & 3));
+            b->digits[((size_t)i * 2 + 1) * b->taps4 + k / 4] |= (uint32_t)(hi & 0xFF) << (8 * (k & 3));
+        }
     return true;
 }
 
@@ -272,6 +392,7 @@ struct psxhip_scaler {
     HostBank h[4];                 // lh, lv, ch, cv
     int32_t* d_left[4] = {nullptr, nullptr, nullptr, nullptr};
     int16_t* d_coef[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_digits[4] = {nullptr, nullptr, nullptr, nullptr};
     ScalerJob job;
     size_t lds_bytes;
     size_t src_bytes;              // bytes of one source picture
@@ -292,6 +413,7 @@ extern "C" void psxhip_scaler_destroy(psxhip_scaler_t* s) {
     for (int i = 0; i < 4; i++) {
         if (s->d_left[i]) (void)hipFree(s->d_left[i]);
         if (s->d_coef[i]) (void)hipFree(s->d_coef[i]);
+        if (s->d_digits[i]) (void)hipFree(s->d_digits[i]);
     }
     delete s;
 }
@@ -353,15 +475,26 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
         reach(s->h[3], dst_height / 2, TH / 2, nullptr, &cr);
         int reg_rows, reg_cols, creg_rows, creg_cols;
         if (yuv) {
-            reg_rows = lr; reg_cols = lc; creg_rows = cr; creg_cols = cc;
+            // every plane's region starts and ends on a multiple of four samples (a lane stages whole dwords)
+            auto reach4 = [](const HostBank& b, int n, int tile) {
+                int best = 0;
+                for (int a = 0; a < n; a += tile) {
+                    const int e = (a + tile < n ? a + tile : n) - 1;
+                    const int lo = b.left[(size_t)a] & ~3, hi = (b.left[(size_t)e] + b.taps + 3) & ~3;
+                    if (hi - lo > best) best = hi - lo;
+                }
+                return best;
+            };
+            reg_rows = lr; reg_cols = reach4(s->h[0], dst_width, TW); creg_rows = cr; creg_cols = reach4(s->h[2], dst_width / 2, TW / 2);
+            (void)lc; (void)cc;
         } else {
             // the union of the luma and the chroma reach over the same full-resolution picture: bounded by the larger span plus
             // the offset between the two windows (at most the larger filter's half width); take the exact maximum over the tiles
             reg_rows = 0; reg_cols = 0;
             for (int a = 0; a < dst_width; a += TW) {
                 const int e = (a + TW < dst_width ? a + TW : dst_width) - 1;
-                const int lo = std::min(s->h[0].left[(size_t)a], s->h[2].left[(size_t)(a / 2)]);
-                const int hi = std::max(s->h[0].left[(size_t)e] + s->h[0].taps, s->h[2].left[(size_t)(e / 2)] + s->h[2].taps);
+                const int lo = std::min(s->h[0].left[(size_t)a], s->h[2].left[(size_t)(a / 2)]) & ~3;       // whole groups of four pixels
+                const int hi = (std::max(s->h[0].left[(size_t)e] + s->h[0].taps, s->h[2].left[(size_t)(e / 2)] + s->h[2].taps) + 3) & ~3;
                 reg_cols = std::max(reg_cols, hi - lo);
             }
             for (int a = 0; a < dst_height; a += TH) {
@@ -372,11 +505,12 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
             }
             creg_rows = reg_rows; creg_cols = reg_cols;
         }
-        const size_t plane = ((size_t)reg_rows * reg_cols + 15) & ~(size_t)15;
-        const size_t cplane = yuv ? (((size_t)creg_rows * creg_cols + 15) & ~(size_t)15) : plane;
+        // + 8: the horizontal pass reads a window as whole dwords, up to 7 bytes past the last tap (zero digits there)
+        const size_t plane = ((size_t)reg_rows * reg_cols + 8 + 15) & ~(size_t)15;
+        const size_t cplane = yuv ? (((size_t)creg_rows * creg_cols + 8 + 15) & ~(size_t)15) : plane;
         const size_t crows_cap = yuv ? (size_t)creg_rows : (size_t)reg_rows;
         need = plane + 2 * cplane + 2 * ((size_t)reg_rows * TW + 2 * crows_cap * (TW / 2)) +
-               2 * ((size_t)TW * s->h[0].taps + (size_t)TH * s->h[1].taps + (size_t)(TW / 2) * s->h[2].taps + (size_t)(TH / 2) * s->h[3].taps) + 4 +
+               8 * ((size_t)TW * s->h[0].taps4 + (size_t)(TW / 2) * s->h[2].taps4) + 2 * ((size_t)TH * s->h[1].taps + (size_t)(TH / 2) * s->h[3].taps) + 4 +
                4 * ((size_t)TW + TH + TW / 2 + TH / 2) + 16;
         if (need * 2 <= (size_t)prop.maxSharedMemoryPerMultiProcessor || (t == 3 && need <= (size_t)prop.maxSharedMemoryPerMultiProcessor)) {
             ok = true;
@@ -396,12 +530,16 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
         HIP_TRY(hipMalloc((void**)&s->d_coef[i], s->h[i].coef.size() * sizeof(int16_t)), PSXHIP_ENOMEM);
         HIP_TRY(hipMemcpy(s->d_left[i], s->h[i].left.data(), s->h[i].left.size() * sizeof(int32_t), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
         HIP_TRY(hipMemcpy(s->d_coef[i], s->h[i].coef.data(), s->h[i].coef.size() * sizeof(int16_t), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+        HIP_TRY(hipMalloc((void**)&s->d_digits[i], s->h[i].digits.size() * sizeof(uint32_t)), PSXHIP_ENOMEM);
+        HIP_TRY(hipMemcpy(s->d_digits[i], s->h[i].digits.data(), s->h[i].digits.size() * sizeof(uint32_t), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
     }
     Bank* banks[4] = {&j.lh, &j.lv, &j.ch, &j.cv};
     for (int i = 0; i < 4; i++) {
         banks[i]->left = s->d_left[i];
         banks[i]->coef = s->d_coef[i];
+        banks[i]->digits = s->d_digits[i];
         banks[i]->taps = s->h[i].taps;
+        banks[i]->taps4 = s->h[i].taps4;
     }
     if (yuv) HIP_TRY(hipFuncSetAttribute((const void*)scaler_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
     else HIP_TRY(hipFuncSetAttribute((const void*)scaler_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prop.maxSharedMemoryPerMultiProcessor), PSXHIP_EDEVICE);
