@@ -120,8 +120,13 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     int32_t* l_all = (int32_t*)(((uintptr_t)(f_cv + CH * job.cv.taps) + 3) & ~(uintptr_t)3);    // lefts: [TW] [TH] [CW] [CH]
     int32_t *l_lh = l_all, *l_lv = l_lh + TW, *l_ch = l_lv + TH, *l_cv = l_ch + CW;
 
-    for (int i = tid; i < tw * 2 * job.lh.taps4; i += 256) g_lh[i] = job.lh.digits[(size_t)X0 * 2 * job.lh.taps4 + i];
-    for (int i = tid; i < cw * 2 * job.ch.taps4; i += 256) g_ch[i] = job.ch.digits[(size_t)cX0 * 2 * job.ch.taps4 + i];
+    // (transposed on the way in: dword q of output column i at [q][i], so that the lanes of a wavefront -- consecutive columns --
+    //  read consecutive dwords; column-major rows of 4 dwords put every eighth lane on the same LDS bank)
+    {
+        const int nl = 2 * job.lh.taps4, nc = 2 * job.ch.taps4;
+        for (int e = tid; e < tw * nl; e += 256) { const int i = e / nl, q = e - i * nl; g_lh[q * TW + i] = job.lh.digits[(size_t)X0 * nl + e]; }
+        for (int e = tid; e < cw * nc; e += 256) { const int i = e / nc, q = e - i * nc; g_ch[q * CW + i] = job.ch.digits[(size_t)cX0 * nc + e]; }
+    }
     for (int i = tid; i < th * job.lv.taps; i += 256) f_lv[i] = job.lv.coef[(size_t)Y0 * job.lv.taps + i];
     for (int i = tid; i < chh * job.cv.taps; i += 256) f_cv[i] = job.cv.coef[(size_t)cY0 * job.cv.taps + i];
     if (tid < tw) l_lh[tid] = job.lh.left[X0 + tid];
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     //      time: the window's bytes are fetched as aligned dwords and shifted into place (v_alignbit), biased to int8 (xor 0x80),
     //      and multiplied by the taps' two int8 digits with v_dot4_i32_i8:
     //      sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).  Exact.
-    auto hpass = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int taps4) -> int {
+    auto hpass = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4) -> int {
         const uint32_t at = (uint32_t)(row * pitch + col);                  // byte offset of the window in the plane
         const uint32_t* w = (const uint32_t*)(plane + (at & ~3u));
         const uint32_t sh = (at & 3u) * 8u;
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         for (int q = 0; q < taps4; q++) {
             const uint32_t nxt = w[q + 1];
             const uint32_t sv = __builtin_amdgcn_alignbit(nxt, cur, sh) ^ 0x80808080u;
-            acc_l = __builtin_amdgcn_sdot4((int)g[q], (int)sv, acc_l, false);
-            acc_h = __builtin_amdgcn_sdot4((int)g[taps4 + q], (int)sv, acc_h, false);
+            acc_l = __builtin_amdgcn_sdot4((int)g[q * gstride], (int)sv, acc_l, false);
+            acc_h = __builtin_amdgcn_sdot4((int)g[(taps4 + q) * gstride], (int)sv, acc_h, false);
             cur = nxt;
         }
         return (acc_h << 8) + acc_l + (128 << 14);
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         DivWalk la(tid, 256, tw);
         for (int item = tid; item < rows * tw; item += 256, la.next()) {
             const int r = la.q, i = la.r;
-            const int acc = hpass(p0, rcols, r + r_off, l_lh[i] + c_off, g_lh + i * 2 * taps4, taps4);
+            const int acc = hpass(p0, rcols, r + r_off, l_lh[i] + c_off, g_lh + i, TW, taps4);
             int t = clampi(acc >> 7, 0, 32767);
             if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
             tmpL[r * TW + i] = (int16_t)t;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         DivWalk ca(tid, 256, cw);
         for (int item = tid; item < 2 * crows * cw; item += 256, ca.next()) {
             const int comp = ca.q >= crows ? 1 : 0, r = ca.q - comp * crows, i = ca.r;      // rows 0..crows-1: Cr, then Cb
-            const int acc = hpass(comp ? p1 : p2, crcols, r + cr_off, l_ch[i] + cc_off, g_ch + i * 2 * ctaps4, ctaps4);      // comp 0 = Cr, 1 = Cb
+            const int acc = hpass(comp ? p1 : p2, crcols, r + cr_off, l_ch[i] + cc_off, g_ch + i, CW, ctaps4);      // comp 0 = Cr, 1 = Cb
             int t = clampi(acc >> 7, 0, 32767);
             if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
             tmpC[((size_t)comp * crows_cap + r) * CW + i] = (int16_t)t;
