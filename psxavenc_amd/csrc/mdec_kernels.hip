@@ -678,7 +678,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
     // hands out the frames after those
     if (tid == 0) {
-        L.scalars[S_FRAME] = (int)blockIdx.x;
+        // Workgroup b runs on XCD b % 8 (observed, not promised), so "first frame = b" hands XCD x exactly the frames = x (mod 8),
+        // and content whose cost has a period of 8 frames -- the synthetic generator shifts its chroma pattern one pixel per
+        // frame, i.e. it re-aligns with the 8x8 block grid every 8 frames -- piles every expensive frame of the first round
+        // on one XCD (traced on noise +-8: the groups of XCD 0 ended at 222 us on average, the others at 172).  Inside each
+        // octet of workgroups the frame <-> workgroup assignment is rotated by the octet's number: every XCD sees all eight
+        // phases, and still a time-interleaved sample of the batch (which is what real, slowly varying video wants).
+        unsigned f0 = blockIdx.x;
+        if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
+        L.scalars[S_FRAME] = (int)f0;
         next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
