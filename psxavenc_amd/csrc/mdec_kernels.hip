@@ -49,6 +49,18 @@ constexpr int kZStride = 64;      // int16 per block in the coefficient tile: co
 constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
 constexpr uint32_t kNoMb = 0xFFFFu;   // pass order entry without a macroblock (the last round of tickets may be partial)
+constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
+// The retry queue's state is one 64-bit word of the ticket buffer, in a cache line of its own: groups in (or past) their last fresh
+// frame | slots reserved | pop tickets drawn, 20 bits each.
+constexpr int kQueueWord = 64;
+constexpr int kQueueReservedShift = 20, kQueueHeadShift = 40;
+constexpr unsigned kQueueMask = 0xFFFFFu;
+// A look at a word other XCDs write: a device-scope load (it bypasses this XCD's L2); after many looks in vain, a read-modify-write
+// -- which is performed at the memory side whatever the caches do -- so that progress never rests on the load's coherence alone.
+template <typename T>
+__device__ __forceinline__ T queue_peek(T* p, int looks) {
+    return looks < 4096 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicOr(p, (T)0);
+}
 
 __constant__ uint16_t c_ac_len16[BS_LUT_SIZE];
 __constant__ uint32_t c_ac_code[BS_LUT_SIZE];
@@ -74,11 +86,15 @@ struct FrameJob {
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
     const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
-    unsigned int* ticket;    // [4]: [0] next frame to hand out, [1] workgroups finished (both self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches)
+    unsigned int* ticket;    // [128]: [0] next frame to hand out, [1] workgroups finished (both self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] the retry queue's state word (self-resetting)
+    unsigned int* retry;     // [retry_cap] retry queue: frame | scale to start from << 24, kRetryEmpty when vacant (NULL: frames are never handed on)
+    int retry_patience;      // looks (about 3 us each) a group without work waits for a frame to be handed on
+    int retry_cap;
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     int ck_margin;               // quarter-pass checkpoint: how far (thousandths of its standard error) a projection has to be on the wrong side
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
+__device__ __forceinline__ unsigned long long* queue_state(const FrameJob& job) { return (unsigned long long*)&job.ticket[kQueueWord]; }
 
 // scalars[] slots (LDS, per workgroup)
 enum {
@@ -107,9 +123,13 @@ enum {
     S_CK_WAVES,         // checkpoint: wavefronts whose sums up to the quarter mark are in
     S_ABORT,            // checkpoint verdict: new guess | pass number << 8 (a verdict of an earlier pass is stale, not reset)
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
+    S_RETRY,            // this frame came from the retry queue: the scale to start from (0: a fresh frame; -1: the queue is empty)
+    S_DEFER,            // the frame goes to the retry queue instead of into another pass here
+    S_QUEUE,            // drawn with the last frame's end when no fresh ticket is left: >= 0 the queue slot to take, -1 nothing will come, <= -2 wait for slot -2 - x
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
     S_HINT_BUDGET,      // ... and its budget
     S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
+    S_SPARE,            // (keeps S_SEARCH 8-byte aligned)
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -691,13 +711,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
+    unsigned settle_due = 0u;        // thread 0: the frame in hand is this group's last fresh one and the waiting groups have not been told yet
     auto end_of_frame = [&](int tid) {
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT) L.scalars[tid] = 0;
+        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE) L.scalars[tid] = 0;
         if (tid == 0) {
             // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
             L.scalars[S_FRAME] = (int)next_ticket;
-            next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
+            const unsigned long long due = settle_due;      // (a last fresh frame that ended without a pass)
+            settle_due = 0u;
+            if (next_ticket < (unsigned)job.n_frames) {
+                next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
+            } else if (job.retry) {
+                // no fresh frame left for this group: in place of the ticket it draws its place in the retry queue (see the top of
+                // the frame loop), in the shadow of the same write-out
+                const unsigned long long w = atomicAdd(queue_state(job), (1ull << kQueueHeadShift) + due) + due;
+                const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
+                L.scalars[S_QUEUE] = reserved > h ? (int)h : ((unsigned)w & kQueueMask) >= gridDim.x ? -1 : -2 - (int)h;
+            }
         }
     };
     for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
@@ -705,8 +736,52 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_SHARED_HINT) L.scalars[tid] = 0;
     __syncthreads();
     for (;;) {
-        const int f = L.scalars[S_FRAME];
-        if (f >= job.n_frames) break;
+        int f = L.scalars[S_FRAME];
+        if (f >= job.n_frames) {
+            // No fresh frame left for this group: frames that other groups handed on instead of running another pass over them
+            // (see the end of the pass loop).  Everything here goes through read-modify-write atomics -- the queue is shared by
+            // groups on all XCDs, whose L2s are not coherent for plain loads.  A group leaves when it finds the queue empty;
+            // whoever pushes later still holds a fresh frame and will come through here itself.
+            if (!job.retry || L.scalars[S_QUEUE] == -1) break;
+            __syncthreads();           // everybody has read S_FRAME
+            if (tid == 0) {
+                // Pop ticket h owns queue slot h.  The state word holds, under one atomic, the pop tickets drawn, the slots
+                // reserved, and the number of groups that have started their last fresh frame (only a group that holds a further
+                // fresh ticket hands a frame on): slot h will be filled iff reserved > h, and never once all groups have settled
+                // with reserved <= h.  Until either holds the group waits -- it has nothing else to do.
+                // The wait is bounded: nothing says all groups of the launch are resident at once (another context's kernel may
+                // share the device), and a group that has not started cannot settle.  A group that runs out of patience marks its
+                // slot abandoned on the way out; whoever reserves that slot later learns it from the exchange and keeps its frame.
+                const int q = L.scalars[S_QUEUE];
+                const unsigned h = q >= 0 ? (unsigned)q : (unsigned)(-2 - q);
+                bool there = q >= 0;
+                for (int looks = 0; !there; looks++) {
+                    const unsigned long long w = queue_peek(queue_state(job), looks);
+                    if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
+                    if (((unsigned)w & kQueueMask) >= gridDim.x) break;
+                    if (looks >= job.retry_patience) {
+                        if (h < (unsigned)job.retry_cap) {
+                            if (atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned) != kRetryEmpty) there = true;      // filled this very moment
+                            else atomicAdd(&job.ticket[1], 0x10000u);          // a note for the group that re-arms the queue
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(64);
+                }
+                int got = -1;
+                if (there) {
+                    unsigned v = kRetryEmpty;
+                    for (int looks = 0; v == kRetryEmpty; looks++) v = queue_peek(&job.retry[h], looks);     // (filled right after it was reserved)
+                    L.scalars[S_FRAME] = (int)(v & 0xFFFFFFu);
+                    got = (int)(v >> 24);
+                    job.retry[h] = kRetryEmpty;          // vacated for the next launch (nobody looks at it again in this one)
+                }
+                L.scalars[S_RETRY] = got;
+            }
+            __syncthreads();
+            if (L.scalars[S_RETRY] < 0) break;
+            f = L.scalars[S_FRAME];
+        }
 
         // thread- and lane-derived values (loop bases, masks, LDS addresses) are re-derived per frame from an opaque copy of
         // the thread index: hoisted out of the frame loop they would be spilled to scratch once per wavefront (4 KB each,
@@ -971,8 +1046,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             hint = sh & 0xFF;
             hint_budget = sh >> 8;
         }
+        const int retry_scale = L.scalars[S_RETRY];
+        if (retry_scale > 0) {             // handed on by another group together with the scale its search wanted next
+            hint = retry_scale;
+            hint_budget = max_size;
+        }
         const bool trust_hint = hint >= 1 && hint <= 63 && hint_budget == max_size;
-        if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
+        if (tid == 0) {
+            L.scalars[S_ABORTS_LEFT] = 2;
+            settle_due = job.retry && retry_scale == 0 && next_ticket >= (unsigned)job.n_frames ? 1u : 0u;
+        }
         if (trust_hint) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
             group_sync(1);
@@ -1095,6 +1178,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         while (!L.scalars[S_DONE]) {
             const int count_scale = L.scalars[S_PASS_COUNT], emit_scale = L.scalars[S_PASS_EMIT];
             n_pass++;
+            if (tid == 0 && settle_due) {
+                // a group without a further fresh ticket hands nothing on any more: the waiting groups may know now (the atomic's
+                // round trip passes under the pass)
+                atomicAdd(queue_state(job), 1ull);
+                settle_due = 0u;
+            }
             if (emit_scale && n_pass > 1) {
                 // a further emitting pass rebuilds the staging area
                 for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
@@ -1462,6 +1551,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (scan_early && wid == 1 && emit_scale && !aborted) scan_offsets(lane);
             if (tid == 0) {
                 MdecSearch st = *srch;
+                // A frame that needs ANOTHER full pass (a wrong first guess) is started from scratch anyway -- the DCT is recomputed,
+                // the staging area rebuilt -- so it need not be this group that does it.  While this group still holds a ticket for
+                // a fresh frame it hands the frame on: (frame, scale to start from) goes into a queue in global memory and the group
+                // moves to its next fresh frame; groups that run out of fresh frames empty the queue (top of the frame loop).  The
+                // launch used to last as long as the group that drew two such frames (noise +-8: 250 us against a median group's
+                // 170); retries are now drawn like tickets.  The result of a frame never depends on who encodes it or from which guess.
+                auto hand_on = [&](const MdecPass& np) -> bool {
+                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || next_ticket >= (unsigned)job.n_frames) return false;
+                    const unsigned slot = (unsigned)(atomicAdd(queue_state(job), 1ull << kQueueReservedShift) >> kQueueReservedShift) & kQueueMask;
+                    if (atomicExch(&job.retry[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
+                        atomicExch(&job.retry[slot], kRetryEmpty);      // the group this slot belonged to has left: the frame stays here
+                        return false;
+                    }
+                    L.scalars[S_DEFER] = 1;
+                    L.scalars[S_DONE] = 1;
+                    L.scalars[S_HINT] = np.emit_scale;       // what this group learned about the neighbourhood stays with it
+                    L.scalars[S_HINT_BUDGET] = max_size;
+                    return true;
+                };
                 if (aborted) {
                     // the pass was cut short: no evaluation to record, the staging area holds a partial stream
                     st.staged = 0;
@@ -1473,6 +1581,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
                     L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
+                    (void)hand_on(np);
                 } else {
                 if (count_scale) {
                     const int tb = L.scalars[S_CNT_F] + fixed_bits;
@@ -1494,6 +1603,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                     if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
+                    (void)hand_on(np);
                 }
                 }
             }
@@ -1501,6 +1611,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         n_done++;
         mark(3);   // passes
+        if (L.scalars[S_DEFER]) {
+            // handed on: nothing of this frame is written here
+            group_sync(5);      // everyone has read the verdict: the scalars may go
+            end_of_frame(tid);
+            group_sync(5);
+            continue;
+        }
         if (STATS && tid == 0 && f < PSXHIP_MDEC_TRACE_FRAMES)      // per-frame record: first guess | first abort verdict << 8 | answer << 16 | passes << 24
             job.stats[PSXHIP_MDEC_STATS_FRAME0 + f] = (unsigned long long)(guess & 0xFF) | (unsigned long long)(first_abort & 0xFF) << 8 |
                                                       (unsigned long long)(L.scalars[S_RESULT] & 0xFF) << 16 | (unsigned long long)n_pass << 24;
@@ -1683,9 +1800,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are
     //      stream-ordered, see psxav_hip.h)
     if (tid == 0) {
-        if (atomicAdd(&job.ticket[1], 1u) == gridDim.x - 1u) {
+        const unsigned left = atomicAdd(&job.ticket[1], 1u);       // groups gone | abandoned queue slots << 16
+        if ((left & 0xFFFFu) == gridDim.x - 1u) {
             job.ticket[0] = 0u;
             job.ticket[1] = 0u;
+            if (job.retry) {           // the retry queue's counters
+                if (left >> 16) {      // slots that were given up and never reserved still say so
+                    const unsigned long long w = atomicAdd(queue_state(job), 0ull);
+                    unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;
+                    if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
+                    for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) job.retry[i] = kRetryEmpty;
+                }
+                *queue_state(job) = 0ull;       // (every slot that was filled has been vacated by the group that took it)
+            }
             __threadfence();
         }
     }
@@ -1815,6 +1942,9 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.max_frame_size = a->max_frame_size;
     job.stg_words = a->stg_words;
     job.ticket = a->d_ticket;
+    job.retry = a->d_retry;
+    job.retry_cap = a->retry_cap;
+    job.retry_patience = a->retry_patience;
     job.stats = a->d_stats;
     job.prio_pattern = a->prio_pattern;
     job.ck_margin = a->ck_margin > 0 ? a->ck_margin : 800;

@@ -75,7 +75,10 @@ struct psxhip_mdec_ctx {
     int groups_max;            // persistent grid size: compute units x resident groups per CU
     int large;                 // 1: one 16-wavefront group per CU (two 12-wavefront groups do not fit the LDS)
     size_t lds_bytes;
-    unsigned int* d_ticket;         // [2] frame hand-out counters (the kernel re-arms them when it ends)
+    unsigned int* d_ticket;         // [128] frame hand-out counters, hint, retry queue pop tickets / state (a cache line each) (the kernel re-arms them when it ends)
+    unsigned int* d_retry;          // retry queue slots (frames a group hands on instead of running another pass over them)
+    int retry_cap;
+    int retry_patience;
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
     int ck_margin;
@@ -223,8 +226,15 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
 
-    HIP_TRY(hipMalloc((void**)&c->d_ticket, 4 * sizeof(unsigned int)), PSXHIP_ENOMEM);
-    HIP_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned int)), PSXHIP_EDEVICE);
+    HIP_TRY(hipMalloc((void**)&c->d_ticket, 128 * sizeof(unsigned int)), PSXHIP_ENOMEM);
+    HIP_TRY(hipMemset(c->d_ticket, 0, 128 * sizeof(unsigned int)), PSXHIP_EDEVICE);
+    if (!getenv("PSXHIP_MDEC_NO_RETRY_QUEUE")) {      // experiments: frames are never handed on
+        c->retry_cap = 1 << 16;
+        c->retry_patience = 256;
+        if (const char* e = getenv("PSXHIP_MDEC_QUEUE_PATIENCE")) c->retry_patience = atoi(e);      // tests: 0 exercises the give-up path
+        HIP_TRY(hipMalloc((void**)&c->d_retry, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_ENOMEM);
+        HIP_TRY(hipMemset(c->d_retry, 0xFF, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_EDEVICE);
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), PSXHIP_EDEVICE);
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->kernel_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
@@ -263,6 +273,7 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_retry) (void)hipFree(c->d_retry);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_order_large) (void)hipFree(c->d_order_large);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -326,6 +337,11 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
     a.large = c->large || small_batch;
     a.stream = stream;
     a.d_ticket = c->d_ticket;
+    // frames are handed on only when a group can hold more than one (else nobody is left to take them) and the queue has a slot per frame
+    const bool queue = c->d_retry && n_frames > a.grid && n_frames < c->retry_cap;
+    a.d_retry = queue ? c->d_retry : nullptr;
+    a.retry_cap = queue ? c->retry_cap : 0;
+    a.retry_patience = c->retry_patience;
     a.d_order = small_batch ? c->d_order_large : c->d_order;
     a.d_stats = c->d_stats;
     a.prio_pattern = c->prio_pattern;

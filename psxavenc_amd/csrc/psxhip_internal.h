@@ -7,7 +7,7 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.0"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.1"
 
 #ifdef __cplusplus
 extern "C" {
@@ -30,7 +30,10 @@ typedef struct {
 	int grid;
 	int large;          /* 1: 16-wavefront groups, one per CU (large frames / budgets) */
 	void *stream;
-	unsigned int *d_ticket;         /* [2] frame hand-out counters, zero between launches */
+	unsigned int *d_ticket;         /* [128] frame hand-out counters, hint, retry queue words: zero between launches */
+	unsigned int *d_retry;          /* [retry_cap] retry queue slots, all 0xFFFFFFFF between launches; NULL = frames are never handed on */
+	int retry_cap;
+	int retry_patience;             /* looks a group without work waits for a handed-on frame before it leaves */
 	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
 	unsigned prio_pattern;          /* see FrameJob */
 	int ck_margin;                  /* checkpoint margin in thousandths of the projection's standard error (0 = default) */

@@ -356,6 +356,55 @@ def test_long_mixed_batch_exercises_hint_checkpoint_and_retry_paths(torch_cuda):
         enc.close()
 
 
+@pytest.mark.parametrize("mode", ["default", "impatient", "off"])
+def test_frames_handed_on_between_workgroups(torch_cuda, monkeypatch, mode):
+    """a frame whose first guess fails is handed to a queue while its workgroup still holds a fresh frame, and taken up by a
+    workgroup that has run out of fresh frames (mdec_kernels.hip, top of the frame loop).  Content whose answer flips between
+    neighbouring frames makes that the common case.  Three settings -- the default, waiting workgroups that give up at once
+    (their slots are marked abandoned; the frame stays with its workgroup), and no queue -- must give the oracle's bytes, launch
+    after launch (the queue re-arms itself), also with two contexts' kernels sharing the device."""
+    import threading
+    torch = torch_cuda
+    from psxavenc_amd import synth
+    monkeypatch.delenv("PSXHIP_MDEC_NO_RETRY_QUEUE", raising=False)
+    monkeypatch.delenv("PSXHIP_MDEC_QUEUE_PATIENCE", raising=False)
+    if mode == "impatient":
+        monkeypatch.setenv("PSXHIP_MDEC_QUEUE_PATIENCE", "0")
+    elif mode == "off":
+        monkeypatch.setenv("PSXHIP_MDEC_NO_RETRY_QUEUE", "1")
+    w, h, n, budget = 320, 240, 1400, 8192
+    rng = np.random.default_rng(77)
+    frames = torch.cat([synth.frames_device(w, h, 1, 200 * i, 200, a) for i, a in enumerate((8, 6, 3, 8, 12, 6, 8))]).cpu().numpy()
+    frames = np.ascontiguousarray(frames[rng.permutation(n)])  # neighbours disagree: many wrong first guesses
+    want, want_res, rc = O.mdec_encode(0, w, h, frames, budget)
+    assert rc == 0
+    encs = [encoder(0, w, h, budget) for _ in range(2)]
+    d = torch.from_numpy(frames).to("cuda:0")
+    outs = [[None] * 4, [None] * 4]
+
+    def work(i):
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for r in range(4):
+                o, q = encs[i].encode_frames_device(d, budget, stream=s)
+                outs[i][r] = (o, q)
+        s.synchronize()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    for i in range(2):
+        for r in range(4):
+            o, q = outs[i][r]
+            assert_same(o.cpu().numpy()[:, :budget], q.cpu().numpy(), want, want_res, "%s ctx %d launch %d" % (mode, i, r))
+    for e in encs:
+        e.close()
+
+
 def test_device_fdct_matches_oracle_on_200k_blocks():
     """the DCT alone, through the entry point tools/check_fdct_vs_ffmpeg.c uses off-box (psxhip_mdec_fdct_host): same
     fdct8_pk / lane mapping / LDS transposes as the frame kernel, against orc_fdct_islow8 on flat, ramp, checkerboard,
