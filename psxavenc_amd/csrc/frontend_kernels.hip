@@ -14,11 +14,14 @@
 // Why it exists: the frame encoder consumes 750 GB/s of NV21 at its headline rate, a PCIe link delivers 50 GB/s.  Pictures
 // that are decoded on the device (or uploaded once at source size) have to become encoder input without leaving HBM.
 //
-// Mapping: HBM-bound streaming work, no matrix shape in it.  One workgroup = one tile of the OUTPUT (64 x 16 luma pixels +
-// the 32 x 8 chroma pairs under them) of one frame; grid = tiles x frames (>> 256 workgroups for any batch).  The source
-// region the tile's filters reach is read ONCE, coalesced, converted (RGB -> Y, Cb, Cr) and parked in LDS as bytes; the
-// horizontal pass runs LDS -> LDS (int16), the vertical pass LDS -> registers, and the tile leaves as dword stores (four
-// luma bytes, or two interleaved Cr,Cb pairs, per lane).  Filter taps of the tile's rows and columns sit in LDS too.
+// Mapping: HBM-bound streaming work, no matrix shape in it.  One workgroup = one BAND of the output -- 64 luma columns (+ the
+// 32 chroma pairs under them) -- of one frame, walked top to bottom in tiles of 16 rows; grid = bands x frames x vertical
+// segments (>> 256 workgroups for any batch; a lone picture is cut into segments so that the chip still fills).  Per tile, the
+// source rows its filters reach AND THE PREVIOUS TILE DID NOT are read, coalesced, converted (RGB -> Y, Cb, Cr) and parked in
+// LDS as bytes; the horizontal pass runs LDS -> LDS into a RING of int16 rows that outlives the tile (a source row is
+// converted and filtered once per band, not once per tile whose vertical taps touch it: at 2:1 that was 1.5x the rows), the
+// vertical pass ring -> registers, and the tile leaves as dword stores (four luma bytes, or two interleaved Cr,Cb pairs, per
+// lane).  The band's horizontal taps sit in LDS for the whole walk, the tile's vertical taps are reloaded per tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,6 +56,7 @@ struct ScalerJob {
     int csw, csh;             // chroma source plane size (sw/2 x sh/2 for YUV420P, sw x sh for RGB)
     int TW, TH;               // luma tile; the chroma tile is TW/2 x TH/2
     int tiles_x, tiles_y;
+    int vsegs;                // vertical segments per band (blockIdx.z): each re-reads the rows its first tile reaches
     int reg_rows, reg_cols;   // LDS region capacity per plane (RGB: the union of the luma and chroma reach; YUV: luma)
     int creg_rows, creg_cols; // ... of a chroma plane (YUV)
 };
@@ -90,35 +94,38 @@ template <int FMT>      // 0 = RGB24, 1 = YUV420P
 __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = (int)threadIdx.x;
-    const int tx = (int)blockIdx.x % job.tiles_x, ty = (int)blockIdx.x / job.tiles_x;
+    const int tx = (int)blockIdx.x;
     const uint8_t* src = job.src + (size_t)blockIdx.y * job.src_stride;
     uint8_t* out = job.out + (size_t)blockIdx.y * job.frame_stride;
     const int TW = job.TW, TH = job.TH, CW = TW >> 1, CH = TH >> 1;
+    // this segment's tiles
+    const int per_seg = (job.tiles_y + job.vsegs - 1) / job.vsegs;
+    const int ty0 = (int)blockIdx.z * per_seg, ty1 = min(job.tiles_y, ty0 + per_seg);
+    if (ty0 >= ty1) return;
 
-    // ---- this tile's output ranges and the source ranges its taps reach
-    const int X0 = tx * TW, X1 = min(job.dw, X0 + TW), Y0 = ty * TH, Y1 = min(job.dh, Y0 + TH);
-    const int tw = X1 - X0, th = Y1 - Y0, cw = tw >> 1, chh = th >> 1;
-    const int cX0 = X0 >> 1, cY0 = Y0 >> 1;
+    // ---- the band's output columns and the source columns their taps reach
+    const int X0 = tx * TW, X1 = min(job.dw, X0 + TW);
+    const int tw = X1 - X0, cw = tw >> 1;
+    const int cX0 = X0 >> 1;
     const int lxa = job.lh.left[X0], lxb = job.lh.left[X1 - 1] + job.lh.taps;
-    const int lya = job.lv.left[Y0], lyb = job.lv.left[Y1 - 1] + job.lv.taps;
     const int cxa = job.ch.left[cX0], cxb = job.ch.left[cX0 + cw - 1] + job.ch.taps;
-    const int cya = job.cv.left[cY0], cyb = job.cv.left[cY0 + chh - 1] + job.cv.taps;
 
-    // ---- LDS: three byte planes, the two intermediates, the tile's taps
+    // ---- LDS: three byte planes (the rows a tile adds), the two rings of intermediates, the taps
     const int plane_bytes = (job.reg_rows * job.reg_cols + 8 + 15) & ~15;
     const int cplane_bytes = FMT == 0 ? plane_bytes : ((job.creg_rows * job.creg_cols + 8 + 15) & ~15);
     uint8_t* p0 = (uint8_t*)smem;
     uint8_t* p1 = p0 + plane_bytes;
     uint8_t* p2 = p1 + cplane_bytes;
-    int16_t* tmpL = (int16_t*)(p2 + cplane_bytes);                               // [reg_rows][TW]
-    int16_t* tmpC = tmpL + (size_t)job.reg_rows * TW;                             // [2][crows][CW]
-    const int crows_cap = FMT == 0 ? job.reg_rows : job.creg_rows;
-    uint32_t* g_lh = (uint32_t*)(tmpC + (size_t)2 * crows_cap * CW);             // [TW][2 * taps4] digit dwords (l.., h..)
+    const int ringL = job.reg_rows, ringC = FMT == 0 ? job.reg_rows : job.creg_rows;      // rows the rings hold
+    int16_t* tmpL = (int16_t*)(p2 + cplane_bytes);                               // [ringL][TW]
+    int16_t* tmpC = tmpL + (size_t)ringL * TW;                                    // [2][ringC][CW]
+    uint32_t* g_lh = (uint32_t*)(tmpC + (size_t)2 * ringC * CW);                 // [TW][2 * taps4] digit dwords (l.., h..)
     uint32_t* g_ch = g_lh + TW * 2 * job.lh.taps4;                                // [CW][2 * taps4]
-    int16_t* f_lv = (int16_t*)(g_ch + CW * 2 * job.ch.taps4);                     // [TH][taps]
-    int16_t* f_cv = f_lv + TH * job.lv.taps;
-    int32_t* l_all = (int32_t*)(((uintptr_t)(f_cv + CH * job.cv.taps) + 3) & ~(uintptr_t)3);    // lefts: [TW] [TH] [CW] [CH]
-    int32_t *l_lh = l_all, *l_lv = l_lh + TW, *l_ch = l_lv + TH, *l_cv = l_ch + CW;
+    int32_t* l_lh = (int32_t*)(g_ch + CW * 2 * job.ch.taps4);                     // [TW]
+    int32_t* l_ch = l_lh + TW;                                                    // [CW]
+    // the vertical tables of a tile, two copies taken in turn (a tile's are loaded while the previous tile's are still read)
+    int32_t* v_tab = l_ch + CW;
+    const int v_words = TH + CH + (TH * job.lv.taps + CH * job.cv.taps + 1) / 2;
 
     // (transposed on the way in: dword q of output column i at [q][i], so that the lanes of a wavefront -- consecutive columns --
     //  read consecutive dwords; column-major rows of 4 dwords put every eighth lane on the same LDS bank)
@@ -127,130 +134,25 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         for (int e = tid; e < tw * nl; e += 256) { const int i = e / nl, q = e - i * nl; g_lh[q * TW + i] = job.lh.digits[(size_t)X0 * nl + e]; }
         for (int e = tid; e < cw * nc; e += 256) { const int i = e / nc, q = e - i * nc; g_ch[q * CW + i] = job.ch.digits[(size_t)cX0 * nc + e]; }
     }
-    for (int i = tid; i < th * job.lv.taps; i += 256) f_lv[i] = job.lv.coef[(size_t)Y0 * job.lv.taps + i];
-    for (int i = tid; i < chh * job.cv.taps; i += 256) f_cv[i] = job.cv.coef[(size_t)cY0 * job.cv.taps + i];
     if (tid < tw) l_lh[tid] = job.lh.left[X0 + tid];
-    if (tid < th) l_lv[tid] = job.lv.left[Y0 + tid];
     if (tid < cw) l_ch[tid] = job.ch.left[cX0 + tid];
-    if (tid < chh) l_cv[tid] = job.cv.left[cY0 + tid];
 
-    // ---- stage the source region: every source byte of the region is read once (edge replication = clamped coordinates)
-    int ya, yb, xa, xb;          // the region of plane 0 (and, RGB, of all three)
-    int rcols, crcols;           // row pitch of the staged planes
+    // the staged columns (whole groups of four samples: a lane moves dwords)
+    int xa, xb, rcols, crcols, cxa4 = 0;
     if (FMT == 0) {
-        // the region starts and ends on multiples of four pixels: a lane converts four pixels = three dwords of the picture
-        // (12 bytes, aligned because a row is 3 * sw bytes and sw a multiple of 4) into one dword of each LDS plane
-        ya = min(lya, cya); yb = max(lyb, cyb);
         xa = min(lxa, cxa) & ~3; xb = (max(lxb, cxb) + 3) & ~3;
-        rcols = xb - xa;
-        crcols = rcols;
-        const int rows = yb - ya, groups = rcols >> 2;
-        const bool aligned = (job.sw & 3) == 0 && (((uintptr_t)src) & 3) == 0;
-        auto convert = [](int R, int G, int B, uint32_t& y, uint32_t& cb, uint32_t& cr) {
-            y = (uint32_t)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
-            cb = (uint32_t)clampi(((-11059 * R - 21709 * G + 32768 * B + 32768) >> 16) + 128, 0, 255);
-            cr = (uint32_t)clampi(((32768 * R - 27439 * G - 5329 * B + 32768) >> 16) + 128, 0, 255);
-        };
-        // kU groups per trip, all their loads issued before the first conversion: a lane that loads, converts and stores one
-        // group at a time spends a memory round trip per group (the first version: 27 of them per tile, 55 % of the kernel's
-        // wave-cycles waiting)
-        constexpr int kU = 4;
-        const int n_items = rows * groups;
-        DivWalk at(tid, 256, groups);
-        for (int base = tid; base < n_items; base += 256 * kU) {
-            uint32_t d[kU][3];
-            bool fast[kU];
-            int sy[kU], x0[kU];
-#pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const int item = base + u * 256;
-                const int r = at.q, g = at.r;
-                at.next();
-                sy[u] = clampi(ya + r, 0, job.sh - 1);
-                x0[u] = xa + 4 * g;
-                fast[u] = item < n_items && aligned && x0[u] >= 0 && x0[u] + 3 < job.sw;
-                d[u][0] = d[u][1] = d[u][2] = 0u;
-                if (fast[u]) {
-                    const uint32_t* q = (const uint32_t*)(src + ((size_t)sy[u] * job.sw + x0[u]) * 3);
-                    d[u][0] = q[0]; d[u][1] = q[1]; d[u][2] = q[2];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const int item = base + u * 256;
-                if (item >= n_items) continue;
-                uint32_t Y = 0, CB = 0, CR = 0;
-                if (fast[u]) {
-                    const uint32_t d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
-                    uint32_t y, cb, cr;
-                    convert((int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), y, cb, cr);
-                    Y = y; CB = cb; CR = cr;
-                    convert((int)(d0 >> 24), (int)(d1 & 255), (int)((d1 >> 8) & 255), y, cb, cr);
-                    Y |= y << 8; CB |= cb << 8; CR |= cr << 8;
-                    convert((int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)(d2 & 255), y, cb, cr);
-                    Y |= y << 16; CB |= cb << 16; CR |= cr << 16;
-                    convert((int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255), (int)(d2 >> 24), y, cb, cr);
-                    Y |= y << 24; CB |= cb << 24; CR |= cr << 24;
-                } else {                              // the picture's edges (clamped coordinates), or an unaligned picture
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint8_t* px = src + ((size_t)sy[u] * job.sw + clampi(x0[u] + k, 0, job.sw - 1)) * 3;
-                        uint32_t y, cb, cr;
-                        convert(px[0], px[1], px[2], y, cb, cr);
-                        Y |= y << (8 * k); CB |= cb << (8 * k); CR |= cr << (8 * k);
-                    }
-                }
-                ((uint32_t*)p0)[item] = Y;            // item = r * groups + g = dword index (rcols = 4 * groups)
-                ((uint32_t*)p1)[item] = CB;
-                ((uint32_t*)p2)[item] = CR;
-            }
-        }
+        rcols = xb - xa; crcols = rcols;
     } else {
-        // every plane's region starts and ends on multiples of four samples: a lane moves whole dwords
-        ya = lya; yb = lyb; xa = lxa & ~3; xb = (lxb + 3) & ~3;
+        xa = lxa & ~3; xb = (lxb + 3) & ~3;
         rcols = xb - xa;
-        const int cxa4 = cxa & ~3, cxb4 = (cxb + 3) & ~3;
-        crcols = cxb4 - cxa4;
-        const uint8_t* Y = src;
-        const uint8_t* U = src + (size_t)job.sw * job.sh;
-        const uint8_t* V = U + (size_t)job.csw * job.csh;
-        auto stage = [&](uint8_t* dst, const uint8_t* plane, int pw, int ph, int y0, int rows, int x0, int cols) {
-            const int groups = cols >> 2, n_items = rows * groups;
-            const bool aligned = (pw & 3) == 0 && (((uintptr_t)plane) & 3) == 0;
-            constexpr int kU = 8;
-            DivWalk at(tid, 256, groups);
-            for (int base = tid; base < n_items; base += 256 * kU) {
-                uint32_t v[kU];
-#pragma unroll
-                for (int u = 0; u < kU; u++) {
-                    const int item = base + u * 256;
-                    const int r = at.q, g = at.r;
-                    at.next();
-                    const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
-                    v[u] = 0u;
-                    if (item < n_items) {
-                        if (aligned && x >= 0 && x + 3 < pw) {
-                            v[u] = *(const uint32_t*)(plane + (size_t)sy * pw + x);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[(size_t)sy * pw + clampi(x + k, 0, pw - 1)] << (8 * k);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kU; u++)
-                    if (base + u * 256 < n_items) ((uint32_t*)dst)[base + u * 256] = v[u];
-            }
-        };
-        stage(p0, Y, job.sw, job.sh, ya, yb - ya, xa, rcols);
-        stage(p1, U, job.csw, job.csh, cya, cyb - cya, cxa4, crcols);      // Cb
-        stage(p2, V, job.csw, job.csh, cya, cyb - cya, cxa4, crcols);      // Cr
+        cxa4 = cxa & ~3;
+        crcols = ((cxb + 3) & ~3) - cxa4;
     }
-    __syncthreads();
+    // ring position of source row r (r may be negative: edge replication reaches above the picture)
+    const int offL = ringL * 128, offC = ringC * 128;
 
-    // ---- horizontal pass, LDS -> LDS: 15-bit intermediates (+ the range expansion of limited-range input).  Four taps at a
-    //      time: the window's bytes are fetched as aligned dwords and shifted into place (v_alignbit), biased to int8 (xor 0x80),
-    //      and multiplied by the taps' two int8 digits with v_dot4_i32_i8:
+    // ---- horizontal pass of one window: four taps at a time; the window's bytes are fetched as aligned dwords and shifted into
+    //      place (v_alignbit), biased to int8 (xor 0x80), and multiplied by the taps' two int8 digits with v_dot4_i32_i8:
     //      sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).  Exact.
     auto hpass = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4) -> int {
         const uint32_t at = (uint32_t)(row * pitch + col);                  // byte offset of the window in the plane
@@ -267,62 +169,199 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         }
         return (acc_h << 8) + acc_l + (128 << 14);
     };
-    {
-        const int rows = lyb - lya, r_off = lya - ya, c_off = -xa, taps4 = job.lh.taps4;
-        DivWalk la(tid, 256, tw);
-        for (int item = tid; item < rows * tw; item += 256, la.next()) {
-            const int r = la.q, i = la.r;
-            const int acc = hpass(p0, rcols, r + r_off, l_lh[i] + c_off, g_lh + i, TW, taps4);
-            int t = clampi(acc >> 7, 0, 32767);
-            if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
-            tmpL[r * TW + i] = (int16_t)t;
-        }
-        const int crows = cyb - cya, cr_off = FMT == 0 ? cya - ya : 0, cc_off = FMT == 0 ? -xa : -(cxa & ~3), ctaps4 = job.ch.taps4;
-        DivWalk ca(tid, 256, cw);
-        for (int item = tid; item < 2 * crows * cw; item += 256, ca.next()) {
-            const int comp = ca.q >= crows ? 1 : 0, r = ca.q - comp * crows, i = ca.r;      // rows 0..crows-1: Cr, then Cb
-            const int acc = hpass(comp ? p1 : p2, crcols, r + cr_off, l_ch[i] + cc_off, g_ch + i, CW, ctaps4);      // comp 0 = Cr, 1 = Cb
-            int t = clampi(acc >> 7, 0, 32767);
-            if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
-            tmpC[((size_t)comp * crows_cap + r) * CW + i] = (int16_t)t;
-        }
-    }
-    __syncthreads();
 
-    // ---- vertical pass, LDS -> registers -> HBM: a lane makes four adjacent luma bytes / two adjacent Cr,Cb pairs
-    {
-        const int taps = job.lv.taps, q = tw >> 2;
-        DivWalk va(tid, 256, q);
-        for (int item = tid; item < th * q; item += 256, va.next()) {
-            const int j = va.q, i4 = va.r * 4;
-            const int16_t* f = f_lv + j * taps;
-            const int16_t* col = tmpL + (size_t)(l_lv[j] - lya) * TW + i4;
-            int a0 = 1 << 20, a1 = 1 << 20, a2 = 1 << 20, a3 = 1 << 20;
-            for (int k = 0; k < taps; k++) {
-                const int c = (int)f[k];
-                const int16_t* t = col + k * TW;
-                a0 += c * (int)t[0]; a1 += c * (int)t[1]; a2 += c * (int)t[2]; a3 += c * (int)t[3];
+    int have_l = -(1 << 30), have_c = -(1 << 30);          // source rows below these are in the rings (luma / chroma stream)
+    for (int ty = ty0; ty < ty1; ty++) {
+        const int Y0 = ty * TH, Y1 = min(job.dh, Y0 + TH);
+        const int th = Y1 - Y0, chh = th >> 1, cY0 = Y0 >> 1;
+        const int lya = job.lv.left[Y0], lyb = job.lv.left[Y1 - 1] + job.lv.taps;
+        const int cya = job.cv.left[cY0], cyb = job.cv.left[cY0 + chh - 1] + job.cv.taps;
+        int32_t* vt = v_tab + ((ty - ty0) & 1) * v_words;
+        int32_t* l_lv = vt;                                   // [TH] ring position of the first tap's row
+        int32_t* l_cv = l_lv + TH;                            // [CH]
+        int16_t* f_lv = (int16_t*)(l_cv + CH);                // [TH][taps]
+        int16_t* f_cv = f_lv + TH * job.lv.taps;              // [CH][ctaps]
+        for (int i = tid; i < th * job.lv.taps; i += 256) f_lv[i] = job.lv.coef[(size_t)Y0 * job.lv.taps + i];
+        for (int i = tid; i < chh * job.cv.taps; i += 256) f_cv[i] = job.cv.coef[(size_t)cY0 * job.cv.taps + i];
+        if (tid < th) l_lv[tid] = (job.lv.left[Y0 + tid] + offL) % ringL;
+        if (tid < chh) l_cv[tid] = (job.cv.left[cY0 + tid] + offC) % ringC;
+
+        // ---- stage the source rows this tile adds: every byte once (edge replication = clamped coordinates)
+        int n0, n1, cn0, cn1;          // new rows of the luma stream (RGB: of all three components) / of the chroma stream (YUV)
+        if (FMT == 0) {
+            // a lane converts four pixels = three dwords of the picture (12 bytes, aligned because a row is 3 * sw bytes and sw a
+            // multiple of 4) into one dword of each LDS plane
+            n0 = max(min(lya, cya), have_l); n1 = max(lyb, cyb);
+            cn0 = n0; cn1 = n1;
+            const int rows = n1 - n0, groups = rcols >> 2;
+            const bool aligned = (job.sw & 3) == 0 && (((uintptr_t)src) & 3) == 0;
+            auto convert = [](int R, int G, int B, uint32_t& y, uint32_t& cb, uint32_t& cr) {
+                y = (uint32_t)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
+                cb = (uint32_t)clampi(((-11059 * R - 21709 * G + 32768 * B + 32768) >> 16) + 128, 0, 255);
+                cr = (uint32_t)clampi(((32768 * R - 27439 * G - 5329 * B + 32768) >> 16) + 128, 0, 255);
+            };
+            // kU groups per trip, all their loads issued before the first conversion: a lane that loads, converts and stores one
+            // group at a time spends a memory round trip per group (the first version: 27 of them per tile, 55 % of the kernel's
+            // wave-cycles waiting)
+            constexpr int kU = 4;
+            const int n_items = rows * groups;
+            DivWalk at(tid, 256, groups);
+            for (int base = tid; base < n_items; base += 256 * kU) {
+                uint32_t d[kU][3];
+                bool fast[kU];
+                int sy[kU], x0[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const int item = base + u * 256;
+                    const int r = at.q, g = at.r;
+                    at.next();
+                    sy[u] = clampi(n0 + r, 0, job.sh - 1);
+                    x0[u] = xa + 4 * g;
+                    fast[u] = item < n_items && aligned && x0[u] >= 0 && x0[u] + 3 < job.sw;
+                    d[u][0] = d[u][1] = d[u][2] = 0u;
+                    if (fast[u]) {
+                        const uint32_t* q = (const uint32_t*)(src + ((size_t)sy[u] * job.sw + x0[u]) * 3);
+                        d[u][0] = q[0]; d[u][1] = q[1]; d[u][2] = q[2];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const int item = base + u * 256;
+                    if (item >= n_items) continue;
+                    uint32_t Y = 0, CB = 0, CR = 0;
+                    if (fast[u]) {
+                        const uint32_t d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
+                        uint32_t y, cb, cr;
+                        convert((int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), y, cb, cr);
+                        Y = y; CB = cb; CR = cr;
+                        convert((int)(d0 >> 24), (int)(d1 & 255), (int)((d1 >> 8) & 255), y, cb, cr);
+                        Y |= y << 8; CB |= cb << 8; CR |= cr << 8;
+                        convert((int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)(d2 & 255), y, cb, cr);
+                        Y |= y << 16; CB |= cb << 16; CR |= cr << 16;
+                        convert((int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255), (int)(d2 >> 24), y, cb, cr);
+                        Y |= y << 24; CB |= cb << 24; CR |= cr << 24;
+                    } else {                              // the picture's edges (clamped coordinates), or an unaligned picture
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint8_t* px = src + ((size_t)sy[u] * job.sw + clampi(x0[u] + k, 0, job.sw - 1)) * 3;
+                            uint32_t y, cb, cr;
+                            convert(px[0], px[1], px[2], y, cb, cr);
+                            Y |= y << (8 * k); CB |= cb << (8 * k); CR |= cr << (8 * k);
+                        }
+                    }
+                    ((uint32_t*)p0)[item] = Y;            // item = r * groups + g = dword index (rcols = 4 * groups)
+                    ((uint32_t*)p1)[item] = CB;
+                    ((uint32_t*)p2)[item] = CR;
+                }
             }
-            const uint32_t v = out8(a0) | out8(a1) << 8 | out8(a2) << 16 | out8(a3) << 24;
-            *(uint32_t*)(out + (size_t)(Y0 + j) * job.dw + X0 + i4) = v;
+        } else {
+            n0 = max(lya, have_l); n1 = lyb;
+            cn0 = max(cya, have_c); cn1 = cyb;
+            const uint8_t* Y = src;
+            const uint8_t* U = src + (size_t)job.sw * job.sh;
+            const uint8_t* V = U + (size_t)job.csw * job.csh;
+            auto stage = [&](uint8_t* dst, const uint8_t* plane, int pw, int ph, int y0, int rows, int x0, int cols) {
+                const int groups = cols >> 2, n_items = rows * groups;
+                const bool aligned = (pw & 3) == 0 && (((uintptr_t)plane) & 3) == 0;
+                constexpr int kU = 8;
+                DivWalk at(tid, 256, groups);
+                for (int base = tid; base < n_items; base += 256 * kU) {
+                    uint32_t v[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        const int item = base + u * 256;
+                        const int r = at.q, g = at.r;
+                        at.next();
+                        const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
+                        v[u] = 0u;
+                        if (item < n_items) {
+                            if (aligned && x >= 0 && x + 3 < pw) {
+                                v[u] = *(const uint32_t*)(plane + (size_t)sy * pw + x);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[(size_t)sy * pw + clampi(x + k, 0, pw - 1)] << (8 * k);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; u++)
+                        if (base + u * 256 < n_items) ((uint32_t*)dst)[base + u * 256] = v[u];
+                }
+            };
+            stage(p0, Y, job.sw, job.sh, n0, n1 - n0, xa, rcols);
+            stage(p1, U, job.csw, job.csh, cn0, cn1 - cn0, cxa4, crcols);      // Cb
+            stage(p2, V, job.csw, job.csh, cn0, cn1 - cn0, cxa4, crcols);      // Cr
         }
-        const int ctaps = job.cv.taps, cq = cw >> 1;
-        uint8_t* cout = out + (size_t)job.dw * job.dh;
-        DivWalk vc(tid, 256, cq);
-        for (int item = tid; item < chh * cq; item += 256, vc.next()) {
-            const int j = vc.q, i2 = vc.r * 2;
-            const int16_t* f = f_cv + j * ctaps;
-            const int16_t* cr = tmpC + (size_t)(l_cv[j] - cya) * CW + i2;
-            const int16_t* cb = cr + (size_t)crows_cap * CW;
-            int r0 = 1 << 20, r1 = 1 << 20, b0 = 1 << 20, b1 = 1 << 20;
-            for (int k = 0; k < ctaps; k++) {
-                const int c = (int)f[k];
-                r0 += c * (int)cr[k * CW]; r1 += c * (int)cr[k * CW + 1];
-                b0 += c * (int)cb[k * CW]; b1 += c * (int)cb[k * CW + 1];
+        have_l = n1; have_c = cn1;
+        __syncthreads();
+
+        // ---- horizontal pass over the new rows, LDS -> the rings: 15-bit intermediates (+ the range expansion of limited-range input)
+        {
+            const int rows = n1 - n0, c_off = -xa, taps4 = job.lh.taps4;
+            const int ring0 = (n0 + offL) % ringL;
+            DivWalk la(tid, 256, tw);
+            for (int item = tid; item < rows * tw; item += 256, la.next()) {
+                const int r = la.q, i = la.r;
+                const int acc = hpass(p0, rcols, r, l_lh[i] + c_off, g_lh + i, TW, taps4);
+                int t = clampi(acc >> 7, 0, 32767);
+                if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
+                int rr = ring0 + r;
+                if (rr >= ringL) rr -= ringL;
+                tmpL[rr * TW + i] = (int16_t)t;
             }
-            // NV21: Cr at even bytes, Cb at odd (mdec.c:627-628)
-            const uint32_t v = out8(r0) | out8(b0) << 8 | out8(r1) << 16 | out8(b1) << 24;
-            *(uint32_t*)(cout + (size_t)(cY0 + j) * job.dw + (size_t)(cX0 + i2) * 2) = v;
+            const int crows = cn1 - cn0, cc_off = FMT == 0 ? -xa : -cxa4, ctaps4 = job.ch.taps4;
+            const int cring0 = (cn0 + offC) % ringC;
+            DivWalk ca(tid, 256, cw);
+            for (int item = tid; item < 2 * crows * cw; item += 256, ca.next()) {
+                const int comp = ca.q >= crows ? 1 : 0, r = ca.q - comp * crows, i = ca.r;      // rows 0..crows-1: Cr, then Cb
+                const int acc = hpass(comp ? p1 : p2, crcols, r, l_ch[i] + cc_off, g_ch + i, CW, ctaps4);      // comp 0 = Cr, 1 = Cb
+                int t = clampi(acc >> 7, 0, 32767);
+                if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
+                int rr = cring0 + r;
+                if (rr >= ringC) rr -= ringC;
+                tmpC[((size_t)comp * ringC + rr) * CW + i] = (int16_t)t;
+            }
+        }
+        __syncthreads();
+
+        // ---- vertical pass, rings -> registers -> HBM: a lane makes four adjacent luma bytes / two adjacent Cr,Cb pairs
+        {
+            const int taps = job.lv.taps, q = tw >> 2;
+            DivWalk va(tid, 256, q);
+            for (int item = tid; item < th * q; item += 256, va.next()) {
+                const int j = va.q, i4 = va.r * 4;
+                const int16_t* f = f_lv + j * taps;
+                int rr = l_lv[j];
+                int a0 = 1 << 20, a1 = 1 << 20, a2 = 1 << 20, a3 = 1 << 20;
+                for (int k = 0; k < taps; k++) {
+                    const int c = (int)f[k];
+                    const int16_t* t = tmpL + rr * TW + i4;
+                    a0 += c * (int)t[0]; a1 += c * (int)t[1]; a2 += c * (int)t[2]; a3 += c * (int)t[3];
+                    rr = rr + 1 == ringL ? 0 : rr + 1;
+                }
+                const uint32_t v = out8(a0) | out8(a1) << 8 | out8(a2) << 16 | out8(a3) << 24;
+                *(uint32_t*)(out + (size_t)(Y0 + j) * job.dw + X0 + i4) = v;
+            }
+            const int ctaps = job.cv.taps, cq = cw >> 1;
+            uint8_t* cout = out + (size_t)job.dw * job.dh;
+            DivWalk vc(tid, 256, cq);
+            for (int item = tid; item < chh * cq; item += 256, vc.next()) {
+                const int j = vc.q, i2 = vc.r * 2;
+                const int16_t* f = f_cv + j * ctaps;
+                int rr = l_cv[j];
+                int r0 = 1 << 20, r1 = 1 << 20, b0 = 1 << 20, b1 = 1 << 20;
+                for (int k = 0; k < ctaps; k++) {
+                    const int c = (int)f[k];
+                    const int16_t* cr = tmpC + rr * CW + i2;
+                    const int16_t* cb = cr + (size_t)ringC * CW;
+                    r0 += c * (int)cr[0]; r1 += c * (int)cr[1];
+                    b0 += c * (int)cb[0]; b1 += c * (int)cb[1];
+                    rr = rr + 1 == ringC ? 0 : rr + 1;
+                }
+                // NV21: Cr at even bytes, Cb at odd (mdec.c:627-628)
+                const uint32_t v = out8(r0) | out8(b0) << 8 | out8(r1) << 16 | out8(b1) << 24;
+                *(uint32_t*)(cout + (size_t)(cY0 + j) * job.dw + (size_t)(cX0 + i2) * 2) = v;
+            }
         }
     }
 }
@@ -401,6 +440,7 @@ struct psxhip_scaler {
     ScalerJob job;
     size_t lds_bytes;
     size_t src_bytes;              // bytes of one source picture
+    int n_cus;
 };
 
 #define HIP_TRY(expr, code)                                                                   \
@@ -456,6 +496,7 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
     j.limited = yuv && !src_full_range;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device), PSXHIP_EDEVICE);
+    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // tile: the largest of these whose LDS working set leaves room for at least two workgroups per CU
     const int shapes[4][2] = {{64, 16}, {32, 16}, {32, 8}, {16, 8}};
     size_t need = 0;
@@ -514,9 +555,9 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
         const size_t plane = ((size_t)reg_rows * reg_cols + 8 + 15) & ~(size_t)15;
         const size_t cplane = yuv ? (((size_t)creg_rows * creg_cols + 8 + 15) & ~(size_t)15) : plane;
         const size_t crows_cap = yuv ? (size_t)creg_rows : (size_t)reg_rows;
+        const size_t v_words = (size_t)TH + TH / 2 + ((size_t)TH * s->h[1].taps + (size_t)(TH / 2) * s->h[3].taps + 1) / 2;      // one tile's vertical tables
         need = plane + 2 * cplane + 2 * ((size_t)reg_rows * TW + 2 * crows_cap * (TW / 2)) +
-               8 * ((size_t)TW * s->h[0].taps4 + (size_t)(TW / 2) * s->h[2].taps4) + 2 * ((size_t)TH * s->h[1].taps + (size_t)(TH / 2) * s->h[3].taps) + 4 +
-               4 * ((size_t)TW + TH + TW / 2 + TH / 2) + 16;
+               8 * ((size_t)TW * s->h[0].taps4 + (size_t)(TW / 2) * s->h[2].taps4) + 4 * ((size_t)TW + TW / 2) + 4 * 2 * v_words + 16;
         if (need * 2 <= (size_t)prop.maxSharedMemoryPerMultiProcessor || (t == 3 && need <= (size_t)prop.maxSharedMemoryPerMultiProcessor)) {
             ok = true;
             j.TW = TW; j.TH = TH;
@@ -582,15 +623,23 @@ extern "C" int psxhip_scaler_convert_device(psxhip_scaler_t* s, const uint8_t* d
     HIP_TRY(hipSetDevice(s->device), PSXHIP_EDEVICE);
     ScalerJob j = s->job;
     j.src = d_src; j.src_stride = src_stride; j.out = d_frames; j.frame_stride = frame_stride;
-    const int tiles = j.tiles_x * j.tiles_y;
+    // a band walks the picture top to bottom; a small batch is cut into vertical segments until the chip has ~4 workgroups per CU
+    // (each segment re-reads the rows its first tile reaches)
+    const long long want = 4LL * s->n_cus;
+    long long segs = (want + (long long)j.tiles_x * n_frames - 1) / ((long long)j.tiles_x * n_frames);
+    if (segs < 1) segs = 1;
+    if (segs > j.tiles_y) segs = j.tiles_y;
+    if (const char* e = getenv("PSXHIP_SCALER_VSEGS")) { segs = atoi(e); if (segs < 1) segs = 1; if (segs > j.tiles_y) segs = j.tiles_y; }   // experiments
+    j.vsegs = (int)segs;
     for (int f0 = 0; f0 < n_frames; f0 += 65535) {            // gridDim.y limit
         const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
         j.src = d_src + (size_t)f0 * src_stride;
         j.out = d_frames + (size_t)f0 * frame_stride;
+        const dim3 grid((unsigned)j.tiles_x, (unsigned)nf, (unsigned)j.vsegs);
         if (s->fmt == PSXHIP_PIX_YUV420P)
-            hipLaunchKernelGGL(scaler_kernel<1>, dim3((unsigned)tiles, (unsigned)nf), dim3(256), s->lds_bytes, (hipStream_t)stream, j);
+            hipLaunchKernelGGL(scaler_kernel<1>, grid, dim3(256), s->lds_bytes, (hipStream_t)stream, j);
         else
-            hipLaunchKernelGGL(scaler_kernel<0>, dim3((unsigned)tiles, (unsigned)nf), dim3(256), s->lds_bytes, (hipStream_t)stream, j);
+            hipLaunchKernelGGL(scaler_kernel<0>, grid, dim3(256), s->lds_bytes, (hipStream_t)stream, j);
     }
     HIP_TRY(hipGetLastError(), PSXHIP_EDEVICE);
     return PSXHIP_OK;

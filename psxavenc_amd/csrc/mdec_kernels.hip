@@ -50,8 +50,8 @@ constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
 constexpr uint32_t kNoMb = 0xFFFFu;   // pass order entry without a macroblock (the last round of tickets may be partial)
 constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
-// The retry queue's state is one 64-bit word of the ticket buffer, in a cache line of its own: groups in (or past) their last fresh
-// frame | slots reserved | pop tickets drawn, 20 bits each.
+// The retry queue's state is one 64-bit word of the ticket buffer, in a cache line of its own: fresh-frame tickets drawn | slots
+// reserved | pop tickets drawn, 20 bits each.
 constexpr int kQueueWord = 64;
 constexpr int kQueueReservedShift = 20, kQueueHeadShift = 40;
 constexpr unsigned kQueueMask = 0xFFFFFu;
@@ -95,6 +95,10 @@ struct FrameJob {
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
 __device__ __forceinline__ unsigned long long* queue_state(const FrameJob& job) { return (unsigned long long*)&job.ticket[kQueueWord]; }
+// the next fresh-frame ticket: with the retry queue the counter is the low field of its state word (what the waiting groups look at)
+__device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) {
+    return job.retry ? (unsigned)atomicAdd(queue_state(job), 1ull) & kQueueMask : atomicAdd(&job.ticket[0], 1u);
+}
 
 // scalars[] slots (LDS, per workgroup)
 enum {
@@ -707,27 +711,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         unsigned f0 = blockIdx.x;
         if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
         L.scalars[S_FRAME] = (int)f0;
-        next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
+        next_ticket = draw_ticket(job) + gridDim.x;
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
-    unsigned settle_due = 0u;        // thread 0: the frame in hand is this group's last fresh one and the waiting groups have not been told yet
     auto end_of_frame = [&](int tid) {
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
         if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE) L.scalars[tid] = 0;
         if (tid == 0) {
             // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
             L.scalars[S_FRAME] = (int)next_ticket;
-            const unsigned long long due = settle_due;      // (a last fresh frame that ended without a pass)
-            settle_due = 0u;
             if (next_ticket < (unsigned)job.n_frames) {
-                next_ticket = atomicAdd(&job.ticket[0], 1u) + gridDim.x;
+                next_ticket = draw_ticket(job) + gridDim.x;
             } else if (job.retry) {
                 // no fresh frame left for this group: in place of the ticket it draws its place in the retry queue (see the top of
                 // the frame loop), in the shadow of the same write-out
-                const unsigned long long w = atomicAdd(queue_state(job), (1ull << kQueueHeadShift) + due) + due;
+                const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
                 const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
-                L.scalars[S_QUEUE] = reserved > h ? (int)h : ((unsigned)w & kQueueMask) >= gridDim.x ? -1 : -2 - (int)h;
+                L.scalars[S_QUEUE] = reserved > h ? (int)h : ((unsigned)w & kQueueMask) >= (unsigned)job.n_frames ? -1 : -2 - (int)h;
             }
         }
     };
@@ -746,11 +747,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             __syncthreads();           // everybody has read S_FRAME
             if (tid == 0) {
                 // Pop ticket h owns queue slot h.  The state word holds, under one atomic, the pop tickets drawn, the slots
-                // reserved, and the number of groups that have started their last fresh frame (only a group that holds a further
-                // fresh ticket hands a frame on): slot h will be filled iff reserved > h, and never once all groups have settled
-                // with reserved <= h.  Until either holds the group waits -- it has nothing else to do.
+                // reserved, and the fresh-frame tickets drawn.  Only a group that holds a further fresh ticket hands a frame on, and
+                // every group draws exactly one ticket that lies past the batch (it stops drawing then): once n_frames tickets are
+                // out -- n_frames - grid real ones and one blank per group -- nobody can push any more.  So slot h will be filled
+                // iff reserved > h, and never once the ticket count has reached n_frames with reserved <= h.  Until either holds
+                // the group waits -- it has nothing else to do.
                 // The wait is bounded: nothing says all groups of the launch are resident at once (another context's kernel may
-                // share the device), and a group that has not started cannot settle.  A group that runs out of patience marks its
+                // share the device), and a group that has not started draws no ticket.  A group that runs out of patience marks its
                 // slot abandoned on the way out; whoever reserves that slot later learns it from the exchange and keeps its frame.
                 const int q = L.scalars[S_QUEUE];
                 const unsigned h = q >= 0 ? (unsigned)q : (unsigned)(-2 - q);
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 for (int looks = 0; !there; looks++) {
                     const unsigned long long w = queue_peek(queue_state(job), looks);
                     if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
-                    if (((unsigned)w & kQueueMask) >= gridDim.x) break;
+                    if (((unsigned)w & kQueueMask) >= (unsigned)job.n_frames) break;
                     if (looks >= job.retry_patience) {
                         if (h < (unsigned)job.retry_cap) {
                             if (atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned) != kRetryEmpty) there = true;      // filled this very moment
@@ -1052,10 +1055,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             hint_budget = max_size;
         }
         const bool trust_hint = hint >= 1 && hint <= 63 && hint_budget == max_size;
-        if (tid == 0) {
-            L.scalars[S_ABORTS_LEFT] = 2;
-            settle_due = job.retry && retry_scale == 0 && next_ticket >= (unsigned)job.n_frames ? 1u : 0u;
-        }
+        if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
         if (trust_hint) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
             group_sync(1);
@@ -1178,12 +1178,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         while (!L.scalars[S_DONE]) {
             const int count_scale = L.scalars[S_PASS_COUNT], emit_scale = L.scalars[S_PASS_EMIT];
             n_pass++;
-            if (tid == 0 && settle_due) {
-                // a group without a further fresh ticket hands nothing on any more: the waiting groups may know now (the atomic's
-                // round trip passes under the pass)
-                atomicAdd(queue_state(job), 1ull);
-                settle_due = 0u;
-            }
             if (emit_scale && n_pass > 1) {
                 // a further emitting pass rebuilds the staging area
                 for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
