@@ -151,23 +151,37 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     // ring position of source row r (r may be negative: edge replication reaches above the picture)
     const int offL = ringL * 128, offC = ringC * 128;
 
-    // ---- horizontal pass of one window: four taps at a time; the window's bytes are fetched as aligned dwords and shifted into
-    //      place (v_alignbit), biased to int8 (xor 0x80), and multiplied by the taps' two int8 digits with v_dot4_i32_i8:
-    //      sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).  Exact.
-    auto hpass = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4) -> int {
-        const uint32_t at = (uint32_t)(row * pitch + col);                  // byte offset of the window in the plane
+    // ---- horizontal pass of one output column over FOUR consecutive rows: four taps at a time; a window's bytes are fetched as
+    //      aligned dwords and shifted into place (v_alignbit), biased to int8 (xor 0x80), and multiplied by the taps' two int8 digits
+    //      with v_dot4_i32_i8: sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).
+    //      Exact.  The column's digits are read once for the four rows (the planes' pitch is a multiple of four bytes, so the
+    //      rows' windows also share their alignment).
+    auto hpass4 = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4, int (&res)[4]) {
+        const uint32_t at = (uint32_t)(__mul24(row, pitch) + col);          // byte offset of the first row's window in the plane
         const uint32_t* w = (const uint32_t*)(plane + (at & ~3u));
         const uint32_t sh = (at & 3u) * 8u;
-        int acc_l = 0, acc_h = 0;
-        uint32_t cur = w[0];
+        const int pw = pitch >> 2;
+        const uint32_t* w1 = w + pw;
+        const uint32_t* w2 = w1 + pw;
+        const uint32_t* w3 = w2 + pw;
+        const uint32_t* gl = g;
+        const uint32_t* gh = g + __mul24(taps4, gstride);
+        int acc_l[4] = {0, 0, 0, 0}, acc_h[4] = {0, 0, 0, 0};
+        uint32_t cur[4] = {w[0], w1[0], w2[0], w3[0]};
         for (int q = 0; q < taps4; q++) {
-            const uint32_t nxt = w[q + 1];
-            const uint32_t sv = __builtin_amdgcn_alignbit(nxt, cur, sh) ^ 0x80808080u;
-            acc_l = __builtin_amdgcn_sdot4((int)g[q * gstride], (int)sv, acc_l, false);
-            acc_h = __builtin_amdgcn_sdot4((int)g[(taps4 + q) * gstride], (int)sv, acc_h, false);
-            cur = nxt;
+            const int dl = (int)*gl, dh = (int)*gh;
+            gl += gstride; gh += gstride;
+            const uint32_t nxt[4] = {w[q + 1], w1[q + 1], w2[q + 1], w3[q + 1]};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t sv = __builtin_amdgcn_alignbit(nxt[r], cur[r], sh) ^ 0x80808080u;
+                acc_l[r] = __builtin_amdgcn_sdot4(dl, (int)sv, acc_l[r], false);
+                acc_h[r] = __builtin_amdgcn_sdot4(dh, (int)sv, acc_h[r], false);
+                cur[r] = nxt[r];
+            }
         }
-        return (acc_h << 8) + acc_l + (128 << 14);
+#pragma unroll
+        for (int r = 0; r < 4; r++) res[r] = (acc_h[r] << 8) + acc_l[r] + (128 << 14);
     };
 
     int have_l = -(1 << 30), have_c = -(1 << 30);          // source rows below these are in the rings (luma / chroma stream)
@@ -218,11 +232,10 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                     sy[u] = clampi(n0 + r, 0, job.sh - 1);
                     x0[u] = xa + 4 * g;
                     fast[u] = item < n_items && aligned && x0[u] >= 0 && x0[u] + 3 < job.sw;
-                    d[u][0] = d[u][1] = d[u][2] = 0u;
-                    if (fast[u]) {
-                        const uint32_t* q = (const uint32_t*)(src + ((size_t)sy[u] * job.sw + x0[u]) * 3);
-                        d[u][0] = q[0]; d[u][1] = q[1]; d[u][2] = q[2];
-                    }
+                    // every lane loads, the others from the picture's first bytes: a load under a branch is waited for before the
+                    // next one is issued (the compiler closes each divergent block with s_waitcnt vmcnt(0))
+                    const uint32_t off = (__umul24((uint32_t)sy[u], (uint32_t)job.sw) + (uint32_t)x0[u]) * 3u;     // < 2^31: pictures are at most 16384 x 16384
+                    __builtin_memcpy(d[u], src + (fast[u] ? off : 0u), 12);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
@@ -230,20 +243,32 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                     if (item >= n_items) continue;
                     uint32_t Y = 0, CB = 0, CR = 0;
                     if (fast[u]) {
+                        // The same three forms on v_dot4_u32_u8: a pixel's bytes (R, G, B, one byte of its neighbour against a zero
+                        // coefficient) times the coefficients' two base-256 digits.  Negative coefficients are applied to the
+                        // complemented byte (-c p = c (255 - p) - 255 c): with R, G complemented Cb's coefficients are 11059, 21709,
+                        // 32768, with G, B complemented Cr's are 32768, 27439, 5329, and either constant comes to
+                        // 32768 + (128 << 16) - 32768 * 255 = 65536.  The sums are >= 65536, so the lower clamp never acts; the upper
+                        // one is a min on the 24-bit sum.  The answer is byte 2 of each sum.
                         const uint32_t d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
-                        uint32_t y, cb, cr;
-                        convert((int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), y, cb, cr);
-                        Y = y; CB = cb; CR = cr;
-                        convert((int)(d0 >> 24), (int)(d1 & 255), (int)((d1 >> 8) & 255), y, cb, cr);
-                        Y |= y << 8; CB |= cb << 8; CR |= cr << 8;
-                        convert((int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)(d2 & 255), y, cb, cr);
-                        Y |= y << 16; CB |= cb << 16; CR |= cr << 16;
-                        convert((int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255), (int)(d2 >> 24), y, cb, cr);
-                        Y |= y << 24; CB |= cb << 24; CR |= cr << 24;
+                        uint32_t px[4] = {d0, __builtin_amdgcn_alignbit(d1, d0, 24), __builtin_amdgcn_alignbit(d2, d1, 16), d2 >> 8};
+                        uint32_t ty[4], tb[4], tr[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t p = px[k], pb = p ^ 0x0000FFFFu, pr = p ^ 0x00FFFF00u;
+                            ty[k] = (__builtin_amdgcn_udot4(p, 76u | 150u << 8 | 29u << 16, 0u, false) << 8) +
+                                    __builtin_amdgcn_udot4(p, 139u | 70u << 8 | 47u << 16, 32768u, false);
+                            tb[k] = min((__builtin_amdgcn_udot4(pb, 43u | 84u << 8 | 128u << 16, 0u, false) << 8) +
+                                        __builtin_amdgcn_udot4(pb, 51u | 205u << 8, 65536u, false), 0xFFFFFFu);
+                            tr[k] = min((__builtin_amdgcn_udot4(pr, 128u | 107u << 8 | 20u << 16, 0u, false) << 8) +
+                                        __builtin_amdgcn_udot4(pr, 47u << 8 | 209u << 16, 65536u, false), 0xFFFFFFu);
+                        }
+                        Y = __builtin_amdgcn_perm(ty[1], ty[0], 0x0c0c0602u) | __builtin_amdgcn_perm(ty[3], ty[2], 0x06020c0cu);
+                        CB = __builtin_amdgcn_perm(tb[1], tb[0], 0x0c0c0602u) | __builtin_amdgcn_perm(tb[3], tb[2], 0x06020c0cu);
+                        CR = __builtin_amdgcn_perm(tr[1], tr[0], 0x0c0c0602u) | __builtin_amdgcn_perm(tr[3], tr[2], 0x06020c0cu);
                     } else {                              // the picture's edges (clamped coordinates), or an unaligned picture
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const uint8_t* px = src + ((size_t)sy[u] * job.sw + clampi(x0[u] + k, 0, job.sw - 1)) * 3;
+                            const uint8_t* px = src + (__umul24((uint32_t)sy[u], (uint32_t)job.sw) + (uint32_t)clampi(x0[u] + k, 0, job.sw - 1)) * 3u;
                             uint32_t y, cb, cr;
                             convert(px[0], px[1], px[2], y, cb, cr);
                             Y |= y << (8 * k); CB |= cb << (8 * k); CR |= cr << (8 * k);
@@ -273,13 +298,14 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                         const int r = at.q, g = at.r;
                         at.next();
                         const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
+                        const uint32_t rowoff = __umul24((uint32_t)sy, (uint32_t)pw);      // (planes are at most 16384 x 16384)
                         v[u] = 0u;
                         if (item < n_items) {
                             if (aligned && x >= 0 && x + 3 < pw) {
-                                v[u] = *(const uint32_t*)(plane + (size_t)sy * pw + x);
+                                v[u] = *(const uint32_t*)(plane + (rowoff + (uint32_t)x));
                             } else {
 #pragma unroll
-                                for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[(size_t)sy * pw + clampi(x + k, 0, pw - 1)] << (8 * k);
+                                for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[rowoff + (uint32_t)clampi(x + k, 0, pw - 1)] << (8 * k);
                             }
                         }
                     }
@@ -296,30 +322,42 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         __syncthreads();
 
         // ---- horizontal pass over the new rows, LDS -> the rings: 15-bit intermediates (+ the range expansion of limited-range input)
+        //      (rows past the last new one in the last group of four read whatever follows in LDS and are not stored)
         {
             const int rows = n1 - n0, c_off = -xa, taps4 = job.lh.taps4;
             const int ring0 = (n0 + offL) % ringL;
             DivWalk la(tid, 256, tw);
-            for (int item = tid; item < rows * tw; item += 256, la.next()) {
-                const int r = la.q, i = la.r;
-                const int acc = hpass(p0, rcols, r, l_lh[i] + c_off, g_lh + i, TW, taps4);
-                int t = clampi(acc >> 7, 0, 32767);
-                if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
-                int rr = ring0 + r;
+            for (int item = tid; item < ((rows + 3) >> 2) * tw; item += 256, la.next()) {
+                const int r4 = la.q * 4, i = la.r;
+                int acc[4];
+                hpass4(p0, rcols, r4, l_lh[i] + c_off, g_lh + i, TW, taps4, acc);
+                int rr = ring0 + r4;
                 if (rr >= ringL) rr -= ringL;
-                tmpL[rr * TW + i] = (int16_t)t;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int t = clampi(acc[r] >> 7, 0, 32767);
+                    if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
+                    if (r4 + r < rows) tmpL[__mul24(rr, TW) + i] = (int16_t)t;
+                    rr = rr + 1 == ringL ? 0 : rr + 1;
+                }
             }
             const int crows = cn1 - cn0, cc_off = FMT == 0 ? -xa : -cxa4, ctaps4 = job.ch.taps4;
             const int cring0 = (cn0 + offC) % ringC;
+            const int cgroups = (crows + 3) >> 2;
             DivWalk ca(tid, 256, cw);
-            for (int item = tid; item < 2 * crows * cw; item += 256, ca.next()) {
-                const int comp = ca.q >= crows ? 1 : 0, r = ca.q - comp * crows, i = ca.r;      // rows 0..crows-1: Cr, then Cb
-                const int acc = hpass(comp ? p1 : p2, crcols, r, l_ch[i] + cc_off, g_ch + i, CW, ctaps4);      // comp 0 = Cr, 1 = Cb
-                int t = clampi(acc >> 7, 0, 32767);
-                if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
-                int rr = cring0 + r;
+            for (int item = tid; item < 2 * cgroups * cw; item += 256, ca.next()) {
+                const int comp = ca.q >= cgroups ? 1 : 0, r4 = (ca.q - comp * cgroups) * 4, i = ca.r;      // groups 0..cgroups-1: Cr, then Cb
+                int acc[4];
+                hpass4(comp ? p1 : p2, crcols, r4, l_ch[i] + cc_off, g_ch + i, CW, ctaps4, acc);      // comp 0 = Cr, 1 = Cb
+                int rr = cring0 + r4;
                 if (rr >= ringC) rr -= ringC;
-                tmpC[((size_t)comp * ringC + rr) * CW + i] = (int16_t)t;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int t = clampi(acc[r] >> 7, 0, 32767);
+                    if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
+                    if (r4 + r < crows) tmpC[__mul24(__mul24(comp, ringC) + rr, CW) + i] = (int16_t)t;
+                    rr = rr + 1 == ringC ? 0 : rr + 1;
+                }
             }
         }
         __syncthreads();
@@ -332,12 +370,15 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                 const int j = va.q, i4 = va.r * 4;
                 const int16_t* f = f_lv + j * taps;
                 int rr = l_lv[j];
+                const int16_t* t = tmpL + __mul24(rr, TW) + i4;
                 int a0 = 1 << 20, a1 = 1 << 20, a2 = 1 << 20, a3 = 1 << 20;
                 for (int k = 0; k < taps; k++) {
                     const int c = (int)f[k];
-                    const int16_t* t = tmpL + rr * TW + i4;
-                    a0 += c * (int)t[0]; a1 += c * (int)t[1]; a2 += c * (int)t[2]; a3 += c * (int)t[3];
-                    rr = rr + 1 == ringL ? 0 : rr + 1;
+                    const uint2 v4 = *(const uint2*)t;                       // four int16 (i4 and TW are multiples of 4)
+                    a0 += c * (int)(int16_t)(v4.x & 0xFFFFu); a1 += c * ((int)v4.x >> 16);
+                    a2 += c * (int)(int16_t)(v4.y & 0xFFFFu); a3 += c * ((int)v4.y >> 16);
+                    rr++; t += TW;
+                    if (rr == ringL) { rr = 0; t = tmpL + i4; }
                 }
                 const uint32_t v = out8(a0) | out8(a1) << 8 | out8(a2) << 16 | out8(a3) << 24;
                 *(uint32_t*)(out + (size_t)(Y0 + j) * job.dw + X0 + i4) = v;
@@ -349,14 +390,16 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                 const int j = vc.q, i2 = vc.r * 2;
                 const int16_t* f = f_cv + j * ctaps;
                 int rr = l_cv[j];
+                const int cb_off = __mul24(ringC, CW);
+                const int16_t* cr = tmpC + __mul24(rr, CW) + i2;
                 int r0 = 1 << 20, r1 = 1 << 20, b0 = 1 << 20, b1 = 1 << 20;
                 for (int k = 0; k < ctaps; k++) {
                     const int c = (int)f[k];
-                    const int16_t* cr = tmpC + rr * CW + i2;
-                    const int16_t* cb = cr + (size_t)ringC * CW;
-                    r0 += c * (int)cr[0]; r1 += c * (int)cr[1];
-                    b0 += c * (int)cb[0]; b1 += c * (int)cb[1];
-                    rr = rr + 1 == ringC ? 0 : rr + 1;
+                    const uint32_t vr = *(const uint32_t*)cr, vb = *(const uint32_t*)(cr + cb_off);      // two int16 each (i2, CW, ringC * CW even)
+                    r0 += c * (int)(int16_t)(vr & 0xFFFFu); r1 += c * ((int)vr >> 16);
+                    b0 += c * (int)(int16_t)(vb & 0xFFFFu); b1 += c * ((int)vb >> 16);
+                    rr++; cr += CW;
+                    if (rr == ringC) { rr = 0; cr = tmpC + i2; }
                 }
                 // NV21: Cr at even bytes, Cb at odd (mdec.c:627-628)
                 const uint32_t v = out8(r0) | out8(b0) << 8 | out8(r1) << 16 | out8(b1) << 24;

@@ -40,16 +40,24 @@ def _pictures(fmt, w, h, n, seed):
     (0, 97, 61, 48, 32, True),            # odd source, tiny target, partial tiles
     (1, 1920, 1080, 336, 192, True),      # 5.7x down: the smaller tile shape
 ])
-def test_scaler_bit_exact_against_the_cpu_statement(fmt, sw, sh, dw, dh, full):
+def test_scaler_bit_exact_against_the_cpu_statement(fmt, sw, sh, dw, dh, full, monkeypatch):
+    """every geometry three ways: the launch's own choice of vertical segments (a handful of pictures: nearly one segment per
+    tile, every tile stages its whole reach), ONE segment (a band walks the whole picture: every tile but the first takes most of
+    its rows from the ring the tiles before it filled), and two."""
     from psxavenc_amd.frontend import Scaler
     pics = _pictures(fmt, sw, sh, 3, seed=sw + dh)
     sc = Scaler(fmt, sw, sh, dw, dh, src_full_range=full)
+    want = O.scaler_convert(fmt, sw, sh, full, dw, dh, pics)
+    for segs in ("1", "2"):
+        monkeypatch.setenv("PSXHIP_SCALER_VSEGS", segs)
+        got = sc.convert_host(pics)
+        assert np.array_equal(got, want), "vertical segments = %s: %d bytes differ" % (segs, int((got != want).sum()))
+    monkeypatch.delenv("PSXHIP_SCALER_VSEGS")
     for which, (s_, d_) in enumerate([(sw, dw), (sh, dh), ((sw // 2) if fmt else sw, dw // 2), ((sh // 2) if fmt else sh, dh // 2)]):
         taps, left, coef = sc.filter(which)
         ot, ol, oc = O.scaler_filter(s_, d_)
         assert taps == ot and np.array_equal(left, ol) and np.array_equal(coef, oc), which
     got = sc.convert_host(pics)
-    want = O.scaler_convert(fmt, sw, sh, full, dw, dh, pics)
     if not np.array_equal(got, want):
         bad = np.nonzero(got != want)
         raise AssertionError("%d bytes differ; first at frame %d byte %d (%d vs %d)" % (bad[0].size, bad[0][0], bad[1][0], got[bad[0][0], bad[1][0]], want[bad[0][0], bad[1][0]]))

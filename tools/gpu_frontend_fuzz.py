@@ -33,12 +33,19 @@ for case in range(n_cases):
     pics = rng.integers(0, 256, (2, nbytes), dtype=np.uint8)
     # smooth half of the picture so that the filters see structure as well as noise
     pics[0, : nbytes // 2] = (np.arange(nbytes // 2) // 7 % 256).astype(np.uint8)
+    # vertical segments per band: the launch's own choice for two pictures is close to one per tile; one segment walks the whole
+    # picture through the ring of intermediates
+    segs = [None, "1", "2", "3"][case % 4]
+    if segs is None:
+        os.environ.pop("PSXHIP_SCALER_VSEGS", None)
+    else:
+        os.environ["PSXHIP_SCALER_VSEGS"] = segs
     got = sc.convert_host(pics)
     want = O.scaler_convert(fmt, sw, sh, full, dw, dh, pics)
     ok = np.array_equal(got, want)
     done += 1
     bad += 0 if ok else 1
-    print("case %3d %s %4dx%-4d -> %4dx%-4d %s %s" % (case, "rgb" if fmt == 0 else "yuv", sw, sh, dw, dh, "full" if full else "limited", "ok" if ok else "MISMATCH (%d bytes)" % int((got != want).sum())), flush=True)
+    print("case %3d %s %4dx%-4d -> %4dx%-4d %s %s" % (case, "rgb" if fmt == 0 else "yuv", sw, sh, dw, dh, ("full" if full else "limited") + " segs " + str(segs), "ok" if ok else "MISMATCH (%d bytes)" % int((got != want).sum())), flush=True)
     sc.close()
 print("front-end fuzz: %d cases compared, %d refused geometries, %d mismatching, %.0f s" % (done, refused, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
