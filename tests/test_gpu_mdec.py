@@ -405,6 +405,33 @@ def test_frames_handed_on_between_workgroups(torch_cuda, monkeypatch, mode):
         e.close()
 
 
+@pytest.mark.parametrize("n", [4096, 4097, 70000])
+def test_launch_sizes_either_side_of_the_queue_limits(torch_cuda, n):
+    """the retry queue serves launches of more than one and at most eight frames per workgroup (512 in flight: 4096 is the last
+    size with it, 4097 the first without) and keeps its counters in 20-bit fields -- 70 000 frames go through the plain 32-bit
+    ticket counter.  Tiny frames with abruptly changing content (wrong first guesses everywhere); a sample against the oracle,
+    and the launch's determinism (same bytes when repeated)."""
+    torch = torch_cuda
+    from psxavenc_amd import synth
+    w, h, budget = 48, 32, 260
+    parts = [synth.frames_device(w, h, 7, 1000 * i, min(1000, n - 1000 * i), (3, 30, 9, 60, 1, 18)[i % 6]) for i in range((n + 999) // 1000)]
+    d = torch.cat(parts)
+    perm = torch.from_numpy(np.random.default_rng(n).permutation(n)).to("cuda:0")
+    d = d[perm].contiguous()
+    enc = encoder(0, w, h, budget)
+    o1, r1 = enc.encode_frames_device(d, budget)
+    o2, r2 = enc.encode_frames_device(d, budget)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    pick = np.unique(np.concatenate([np.arange(0, n, max(1, n // 600)), np.arange(n - 40, n), np.arange(40)]))
+    fr = d[torch.from_numpy(pick).to("cuda:0")].cpu().numpy()
+    want, want_res, rc = O.mdec_encode(0, w, h, np.ascontiguousarray(fr), budget)
+    assert rc == 0
+    assert_same(o1[torch.from_numpy(pick).to("cuda:0")].cpu().numpy()[:, :budget], r1[torch.from_numpy(pick).to("cuda:0")].cpu().numpy(), want, want_res, "n=%d" % n)
+    assert len(set(r1[:, 0].cpu().numpy().tolist())) > 3
+    enc.close()
+
+
 def test_device_fdct_matches_oracle_on_200k_blocks():
     """the DCT alone, through the entry point tools/check_fdct_vs_ffmpeg.c uses off-box (psxhip_mdec_fdct_host): same
     fdct8_pk / lane mapping / LDS transposes as the frame kernel, against orc_fdct_islow8 on flat, ramp, checkerboard,
