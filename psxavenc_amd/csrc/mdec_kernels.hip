@@ -50,11 +50,13 @@ constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
 constexpr uint32_t kNoMb = 0xFFFFu;   // pass order entry without a macroblock (the last round of tickets may be partial)
 constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
-// The retry queue's state is one 64-bit word of the ticket buffer, in a cache line of its own: fresh-frame tickets drawn | slots
-// reserved | pop tickets drawn, 20 bits each.
+// Frame tickets and the retry queue's state share one 64-bit word of the ticket buffer, in a cache line of its own: fresh-frame
+// tickets drawn (low 32 bits) | queue slots reserved (16 bits) | pop tickets drawn (16 bits).  (The queue is only used for launches
+// of at most 8 frames per group, so 16 bits are plenty; the ticket counter is the word's low half so that a draw needs no
+// arithmetic on the returned value -- anything computed from it on the spot would make the compiler wait for the atomic there.)
 constexpr int kQueueWord = 64;
-constexpr int kQueueReservedShift = 20, kQueueHeadShift = 40;
-constexpr unsigned kQueueMask = 0xFFFFFu;
+constexpr int kQueueReservedShift = 32, kQueueHeadShift = 48;
+constexpr unsigned kQueueMask = 0xFFFFu;
 // A look at a word other XCDs write: a device-scope load (it bypasses this XCD's L2); after many looks in vain, a read-modify-write
 // -- which is performed at the memory side whatever the caches do -- so that progress never rests on the load's coherence alone.
 template <typename T>
@@ -86,7 +88,7 @@ struct FrameJob {
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
     const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
-    unsigned int* ticket;    // [128]: [0] next frame to hand out, [1] workgroups finished (both self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] the retry queue's state word (self-resetting)
+    unsigned int* ticket;    // [128]: [1] workgroups finished (self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] frame tickets + the retry queue's state, one 64-bit word (self-resetting)
     unsigned int* retry;     // [retry_cap] retry queue: frame | scale to start from << 24, kRetryEmpty when vacant (NULL: frames are never handed on)
     int retry_patience;      // looks (about 3 us each) a group without work waits for a frame to be handed on
     int retry_cap;
@@ -95,10 +97,8 @@ struct FrameJob {
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
 __device__ __forceinline__ unsigned long long* queue_state(const FrameJob& job) { return (unsigned long long*)&job.ticket[kQueueWord]; }
-// the next fresh-frame ticket: with the retry queue the counter is the low field of its state word (what the waiting groups look at)
-__device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) {
-    return job.retry ? (unsigned)atomicAdd(queue_state(job), 1ull) & kQueueMask : atomicAdd(&job.ticket[0], 1u);
-}
+// the next fresh-frame ticket: the low half of the state word (what the waiting groups look at)
+__device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) { return (unsigned)atomicAdd(queue_state(job), 1ull); }
 
 // scalars[] slots (LDS, per workgroup)
 enum {
@@ -698,7 +698,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const bool scan_early = nmb <= 512;
     int n_done = 0;
     if (STATS) t_start = t_mark = wall_clock64();
-    unsigned next_ticket = 0;          // thread 0: drawn one frame ahead, so the atomic's latency hides behind a frame's work
+    // thread 0: the ticket for the frame after next, drawn one frame ahead and kept AS DRAWN (ticket - gridDim.x): nothing is computed
+    // from it before the next frame's decisions, so the atomic's round trip hides behind a frame's work (adding gridDim.x -- a
+    // scalar load -- on the spot made the compiler wait for the atomic right there, at every frame's end)
+    unsigned next_draw = 0;
+    const unsigned fresh_draws = (unsigned)job.n_frames - gridDim.x;      // draws below this are real frames (grid <= n_frames)
     // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
     // hands out the frames after those
     if (tid == 0) {
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         unsigned f0 = blockIdx.x;
         if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
         L.scalars[S_FRAME] = (int)f0;
-        next_ticket = draw_ticket(job) + gridDim.x;
+        next_draw = draw_ticket(job);
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
@@ -720,15 +724,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE) L.scalars[tid] = 0;
         if (tid == 0) {
             // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
-            L.scalars[S_FRAME] = (int)next_ticket;
-            if (next_ticket < (unsigned)job.n_frames) {
-                next_ticket = draw_ticket(job) + gridDim.x;
+            L.scalars[S_FRAME] = (int)(next_draw + gridDim.x);
+            if (next_draw < fresh_draws) {
+                next_draw = draw_ticket(job);
             } else if (job.retry) {
                 // no fresh frame left for this group: in place of the ticket it draws its place in the retry queue (see the top of
                 // the frame loop), in the shadow of the same write-out
                 const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
                 const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
-                L.scalars[S_QUEUE] = reserved > h ? (int)h : ((unsigned)w & kQueueMask) >= (unsigned)job.n_frames ? -1 : -2 - (int)h;
+                L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_frames ? -1 : -2 - (int)h;
             }
         }
     };
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 for (int looks = 0; !there; looks++) {
                     const unsigned long long w = queue_peek(queue_state(job), looks);
                     if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
-                    if (((unsigned)w & kQueueMask) >= (unsigned)job.n_frames) break;
+                    if ((unsigned)w >= (unsigned)job.n_frames) break;
                     if (looks >= job.retry_patience) {
                         if (h < (unsigned)job.retry_cap) {
                             if (atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned) != kRetryEmpty) there = true;      // filled this very moment
@@ -1552,7 +1556,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // launch used to last as long as the group that drew two such frames (noise +-8: 250 us against a median group's
                 // 170); retries are now drawn like tickets.  The result of a frame never depends on who encodes it or from which guess.
                 auto hand_on = [&](const MdecPass& np) -> bool {
-                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || next_ticket >= (unsigned)job.n_frames) return false;
+                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || next_draw >= fresh_draws) return false;
                     const unsigned slot = (unsigned)(atomicAdd(queue_state(job), 1ull << kQueueReservedShift) >> kQueueReservedShift) & kQueueMask;
                     if (atomicExch(&job.retry[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
                         atomicExch(&job.retry[slot], kRetryEmpty);      // the group this slot belonged to has left: the frame stays here
@@ -1796,17 +1800,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     if (tid == 0) {
         const unsigned left = atomicAdd(&job.ticket[1], 1u);       // groups gone | abandoned queue slots << 16
         if ((left & 0xFFFFu) == gridDim.x - 1u) {
-            job.ticket[0] = 0u;
             job.ticket[1] = 0u;
-            if (job.retry) {           // the retry queue's counters
-                if (left >> 16) {      // slots that were given up and never reserved still say so
-                    const unsigned long long w = atomicAdd(queue_state(job), 0ull);
-                    unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;
-                    if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
-                    for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) job.retry[i] = kRetryEmpty;
-                }
-                *queue_state(job) = 0ull;       // (every slot that was filled has been vacated by the group that took it)
+            if (job.retry && (left >> 16)) {      // queue slots that were given up and never reserved still say so
+                const unsigned long long w = atomicAdd(queue_state(job), 0ull);
+                unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;
+                if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
+                for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) job.retry[i] = kRetryEmpty;
             }
+            *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
             __threadfence();
         }
     }
