@@ -18,6 +18,9 @@
  * (Loeffler/Ligtenberg/Moschytz, 13-bit constants, 4 extra bits kept after the row
  * pass), as specialised for 8-bit samples in libavcodec/jfdctint_template.c
  * (ff_jpeg_fdct_islow_8).  Everything downstream of the DCT follows mdec.c directly.
+ * The butterfly's text is held, with 2 extra bits instead of 4, to the compiled IJG original that IS in
+ * this image (libjpeg-turbo's jpeg_fdct_islow; tests/test_fdct_vs_libjpeg.py, bit for bit) -- which checks
+ * the algorithm, not libavcodec's choice of that constant.
  *
  * Built WITHOUT -ffast-math on purpose: DIVIDE_ROUNDED (mdec.c:438) is
  * round-half-away-from-zero of an exactly representable quotient neighbourhood, which
@@ -34,8 +37,8 @@
 /* ------------------------------------------------------------------------------------
  * 8x8 forward DCT, jfdctint "islow" for 8-bit samples (see header comment).
  * One generic 1-D butterfly; the two passes differ only in their output scaling:
- *   rows:    even outputs << 4,             odd/rotated outputs descaled by 13-4
- *   columns: even outputs descaled by 4,    odd/rotated outputs descaled by 13+4
+ *   rows:    even outputs << P,             odd/rotated outputs descaled by 13-P
+ *   columns: even outputs descaled by P,    odd/rotated outputs descaled by 13+P      (P = 4: see orc_fdct_islow8_pass1)
  * and every result is stored back as int16 between and after the passes.
  * ---------------------------------------------------------------------------------- */
 enum {
@@ -47,7 +50,7 @@ enum {
 
 static inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-static void fdct_1d(int16_t *p, int stride, int column_pass) {
+static void fdct_1d(int16_t *p, int stride, int column_pass, int pass1) {
 	const int32_t d0 = p[0 * stride], d1 = p[1 * stride], d2 = p[2 * stride], d3 = p[3 * stride];
 	const int32_t d4 = p[4 * stride], d5 = p[5 * stride], d6 = p[6 * stride], d7 = p[7 * stride];
 
@@ -57,14 +60,14 @@ static void fdct_1d(int16_t *p, int stride, int column_pass) {
 	/* odd half */
 	int32_t o0 = d3 - d4, o1 = d2 - d5, o2 = d1 - d6, o3 = d0 - d7;
 
-	const int rot_shift = column_pass ? 13 + 4 : 13 - 4;
+	const int rot_shift = column_pass ? 13 + pass1 : 13 - pass1;
 
 	if (column_pass) {
-		p[0 * stride] = (int16_t)descale(e0 + e1, 4);
-		p[4 * stride] = (int16_t)descale(e0 - e1, 4);
+		p[0 * stride] = (int16_t)descale(e0 + e1, pass1);
+		p[4 * stride] = (int16_t)descale(e0 - e1, pass1);
 	} else {
-		p[0 * stride] = (int16_t)((e0 + e1) * 16);
-		p[4 * stride] = (int16_t)((e0 - e1) * 16);
+		p[0 * stride] = (int16_t)((e0 + e1) * (1 << pass1));
+		p[4 * stride] = (int16_t)((e0 - e1) * (1 << pass1));
 	}
 	const int32_t r = (e2 + e3) * C_0_541196100;
 	p[2 * stride] = (int16_t)descale(r + e3 * C_0_765366865, rot_shift);
@@ -86,10 +89,17 @@ static void fdct_1d(int16_t *p, int stride, int column_pass) {
 	p[1 * stride] = (int16_t)descale(o3 + z1 + z4, rot_shift);
 }
 
-void orc_fdct_islow8(int16_t *blk) {
-	for (int r = 0; r < 8; r++) fdct_1d(blk + 8 * r, 1, 0);
-	for (int c = 0; c < 8; c++) fdct_1d(blk + c, 8, 1);
+/* The same butterfly with `pass1` extra bits kept after the row pass: 4 is libavcodec's choice for 8-bit samples
+ * (jfdctint_template.c: PASS1_BITS 4, OUT_SHIFT = PASS1_BITS), 2 is the IJG original's (jfdctint.c, release 6b: PASS1_BITS 2),
+ * whose compiled form IS in this image -- libjpeg-turbo exports jpeg_fdct_islow -- and tests/test_fdct_vs_libjpeg.py holds the
+ * pass1 = 2 instance of this text to it bit for bit.  What stays unchecked is only that libavcodec 8.0.1's build differs from
+ * the IJG text in that one constant and nothing else. */
+void orc_fdct_islow8_pass1(int16_t *blk, int pass1) {
+	for (int r = 0; r < 8; r++) fdct_1d(blk + 8 * r, 1, 0, pass1);
+	for (int c = 0; c < 8; c++) fdct_1d(blk + c, 8, 1, pass1);
 }
+
+void orc_fdct_islow8(int16_t *blk) { orc_fdct_islow8_pass1(blk, 4); }
 
 /* ------------------------------------------------------------------------------------
  * VLC maps, same shape as the reference's: (bits << 24) | value, AC indexed by

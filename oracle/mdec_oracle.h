@@ -26,6 +26,7 @@ typedef struct {
 } orc_str_state_t;
 
 void orc_fdct_islow8(int16_t *blk);
+void orc_fdct_islow8_pass1(int16_t *blk, int pass1);   /* 4 = orc_fdct_islow8; 2 = the IJG original (checked against libjpeg-turbo) */
 uint32_t orc_mdec_ac_code(int run, int level);
 uint32_t orc_mdec_dc_code(int comp, int delta);
 void orc_mdec_frame_to_coefs(int w, int h, const uint8_t *nv21, int16_t *coefs);
