@@ -99,6 +99,21 @@ int main(int argc, char **argv) {
 	printf("AVDCT.fdct vs oracle restatement (orc_fdct_islow8): %ld of %zu coefficients differ, max |diff| %ld  -> %s\n",
 	       bad_orc, (size_t)n * 64, max_orc, bad_orc ? "NOT PINNED (is this build's fdct ff_jpeg_fdct_islow_8? try `islow`)" : "PINNED");
 	int rc = bad_orc ? 1 : 0;
+	if (bad_orc) {
+		/* which instance of the IJG butterfly is it then?  (2 extra bits after the row pass = the IJG original, what libjpeg
+		 * ships; 4 = libavcodec's jfdctint_template.c for 8-bit samples, what the oracle assumes) */
+		for (int p1 = 1; p1 <= 5; p1++) {
+			long bad = 0;
+			for (int i = 0; i < n; i++) {
+				int16_t t[64];
+				memcpy(t, in + (size_t)i * 64, sizeof t);
+				orc_fdct_islow8_pass1(t, p1);
+				for (int k = 0; k < 64; k++) bad += t[k] != ff[(size_t)i * 64 + k];
+			}
+			printf("  ... against the same butterfly with %d extra bits after the row pass: %ld coefficients differ%s\n", p1, bad,
+			       bad ? "" : "  <- this build's fdct");
+		}
+	}
 #ifdef WITH_DEVICE
 	int16_t *dev = malloc((size_t)n * 64 * sizeof(int16_t));
 	if (psxhip_mdec_fdct_host(0, in, n, dev) != 0) {
