@@ -260,6 +260,8 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
             HIP_TRY(hipMemset(c->d_stats, 0, PSXHIP_MDEC_STATS_TOTAL * sizeof(unsigned long long)), PSXHIP_EDEVICE);
         }
     }
+    // the fills above ran on the null stream; the context's launches go to streams that do not wait for it
+    HIP_TRY(hipStreamSynchronize(nullptr), PSXHIP_EDEVICE);
     guard.p = nullptr;                   // ownership passes to the caller
     *out = c;
     return PSXHIP_OK;
