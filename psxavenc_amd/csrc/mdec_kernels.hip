@@ -55,6 +55,7 @@ constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
 // of at most 8 frames per group, so 16 bits are plenty; the ticket counter is the word's low half so that a draw needs no
 // arithmetic on the returned value -- anything computed from it on the spot would make the compiler wait for the atomic there.)
 constexpr int kQueueWord = 64;
+constexpr int kStartedWord = 96;         // groups of this launch that have started (a cache line of its own; self-resetting)
 constexpr int kQueueReservedShift = 32, kQueueHeadShift = 48;
 constexpr unsigned kQueueMask = 0xFFFFu;
 // A look at a word other XCDs write: a device-scope load (it bypasses this XCD's L2); after many looks in vain, a read-modify-write
@@ -88,7 +89,7 @@ struct FrameJob {
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
     const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
-    unsigned int* ticket;    // [128]: [1] workgroups finished (self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] frame tickets + the retry queue's state, one 64-bit word (self-resetting)
+    unsigned int* ticket;    // [128]: [1] workgroups finished (self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] frame tickets + the retry queue's state, one 64-bit word, [96] groups started (self-resetting)
     unsigned int* retry;     // [retry_cap] retry queue: frame | scale to start from << 24, kRetryEmpty when vacant (NULL: frames are never handed on)
     int retry_patience;      // looks (about 3 us each) a group without work waits for a frame to be handed on
     int retry_cap;
@@ -716,6 +717,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
         L.scalars[S_FRAME] = (int)f0;
         next_draw = draw_ticket(job);
+        if (job.retry) atomicAdd(&job.ticket[kStartedWord], 1u);      // (nobody waits for a frame to be handed on before all groups are here)
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
@@ -756,17 +758,21 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // out -- n_frames - grid real ones and one blank per group -- nobody can push any more.  So slot h will be filled
                 // iff reserved > h, and never once the ticket count has reached n_frames with reserved <= h.  Until either holds
                 // the group waits -- it has nothing else to do.
-                // The wait is bounded: nothing says all groups of the launch are resident at once (another context's kernel may
-                // share the device), and a group that has not started draws no ticket.  A group that runs out of patience marks its
-                // slot abandoned on the way out; whoever reserves that slot later learns it from the exchange and keeps its frame.
+                // Nothing says all groups of the launch are resident at once (another context's kernel may share the device), and a
+                // group that has not started draws no ticket -- it may even be waiting for the place this group holds.  So a group
+                // waits only once every group of the launch has started, and not for ever; a group that leaves marks its slot
+                // abandoned on the way out, and whoever reserves that slot later learns it from the exchange and keeps its frame.
+                // (Two contexts' launches sharing the GPU ran 4x slower while waiting groups sat out their patience.)
                 const int q = L.scalars[S_QUEUE];
                 const unsigned h = q >= 0 ? (unsigned)q : (unsigned)(-2 - q);
                 bool there = q >= 0;
                 for (int looks = 0; !there; looks++) {
                     const unsigned long long w = queue_peek(queue_state(job), looks);
+                    const unsigned started = queue_peek(&job.ticket[kStartedWord], looks);
                     if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
                     if ((unsigned)w >= (unsigned)job.n_frames) break;
-                    if (looks >= job.retry_patience) {
+                    // a group that has not started may be waiting for THIS group's place on a CU: then nobody waits
+                    if (started < gridDim.x || looks >= job.retry_patience) {
                         if (h < (unsigned)job.retry_cap) {
                             if (atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned) != kRetryEmpty) there = true;      // filled this very moment
                             else atomicAdd(&job.ticket[1], 0x10000u);          // a note for the group that re-arms the queue
@@ -1801,6 +1807,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const unsigned left = atomicAdd(&job.ticket[1], 1u);       // groups gone | abandoned queue slots << 16
         if ((left & 0xFFFFu) == gridDim.x - 1u) {
             job.ticket[1] = 0u;
+            job.ticket[kStartedWord] = 0u;
             if (job.retry && (left >> 16)) {      // queue slots that were given up and never reserved still say so
                 const unsigned long long w = atomicAdd(queue_state(job), 0ull);
                 unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;

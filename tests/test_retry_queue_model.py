@@ -19,6 +19,7 @@ class Shared:
         self.tickets = self.reserved = self.head = 0          # the state word's three fields (one atomic word in the kernel)
         self.slots = [EMPTY] * cap
         self.left = 0                                         # groups gone | abandonments << 16
+        self.started = 0                                      # groups that have started
         self.n, self.grid = n_frames, grid
         self.encoded = [0] * n_frames                         # times a frame was encoded to the end
         self.passes = 0
@@ -30,6 +31,7 @@ def group(S, b, rng, p_wrong, patience, start_delay):
         yield "not started"
     frame, retried = b, False
     next_draw = S.tickets; S.tickets += 1; yield "draw"                       # atomicAdd(state, 1)
+    S.started += 1; yield "started"
     fresh_draws = S.n - S.grid
     while True:
         # ---- one frame: passes until the search is done; a wrong first guess on a fresh frame may be handed on
@@ -66,12 +68,12 @@ def group(S, b, rng, p_wrong, patience, start_delay):
         there = queue >= 0
         looks = 0
         while not there:
-            reserved, tickets = S.reserved, S.tickets; yield "look"
+            reserved, tickets, started = S.reserved, S.tickets, S.started; yield "look"
             if reserved > h:
                 there = True; break
             if tickets >= S.n:
                 break
-            if looks >= patience:
+            if started < S.grid or looks >= patience:            # nobody waits while a group has yet to start
                 old = S.slots[h]                                              # atomicCAS(slot, EMPTY, ABANDONED)
                 if old == EMPTY:
                     S.slots[h] = ABANDONED; yield "abandon"
@@ -95,7 +97,7 @@ def group(S, b, rng, p_wrong, patience, start_delay):
         if left >> 16:
             for i in range(S.reserved, min(S.head, len(S.slots))):
                 S.slots[i] = EMPTY
-        S.tickets = S.reserved = S.head = 0
+        S.tickets = S.reserved = S.head = S.started = 0
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -119,7 +121,7 @@ def test_every_frame_once_everybody_leaves_counters_rearmed(seed):
         steps += 1
         assert steps < 2_000_000, "somebody never leaves"
     assert S.encoded == [1] * n, (seed, [k for k, c in enumerate(S.encoded) if c != 1][:8])
-    assert (S.tickets, S.reserved, S.head, S.left) == (0, 0, 0, 0)
+    assert (S.tickets, S.reserved, S.head, S.left, S.started) == (0, 0, 0, 0, 0)
     assert all(s == EMPTY for s in S.slots), (seed, [(k, hex(s)) for k, s in enumerate(S.slots) if s != EMPTY][:4])
 
 
