@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const int item = base + u * 256;
+                    if (item - tid >= n_items) break;             // (uniform: no lane has an item in this slot or the ones after)
                     const int r = at.q, g = at.r;
                     at.next();
                     sy[u] = clampi(n0 + r, 0, job.sh - 1);
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const int item = base + u * 256;
+                    if (item - tid >= n_items) break;
                     if (item >= n_items) continue;
                     uint32_t Y = 0, CB = 0, CR = 0;
                     if (fast[u]) {
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
 #pragma unroll
                     for (int u = 0; u < kU; u++) {
                         const int item = base + u * 256;
+                        if (item - tid >= n_items) break;         // (uniform: no lane has an item in this slot or the ones after)
                         const int r = at.q, g = at.r;
                         at.next();
                         const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
@@ -310,8 +313,10 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < kU; u++)
+                    for (int u = 0; u < kU; u++) {
+                        if (base - tid + u * 256 >= n_items) break;
                         if (base + u * 256 < n_items) ((uint32_t*)dst)[base + u * 256] = v[u];
+                    }
                 }
             };
             stage(p0, Y, job.sw, job.sh, n0, n1 - n0, xa, rcols);
