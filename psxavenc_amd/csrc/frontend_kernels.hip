@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "psxhip_internal.h"
@@ -156,7 +157,11 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     //      with v_dot4_i32_i8: sum c s = 256 * sum h (s - 128) + sum l (s - 128) + 128 * 16384 (every row of taps sums to 16384).
     //      Exact.  The column's digits are read once for the four rows (the planes' pitch is a multiple of four bytes, so the
     //      rows' windows also share their alignment).
-    auto hpass4 = [&](const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4, int (&res)[4]) {
+    //      `fixed` carries the number of tap dwords when it is one of the common ones (1: no scaling, 2: 2x down, 3, 4: 4x down):
+    //      the loop is then unrolled -- window dwords at immediate offsets, no rotation of the current dword through registers,
+    //      no pointer arithmetic (the rolled loop spent 22 of its 38 instructions per four rows and tap dword on those).
+    auto hpass4 = [&](auto fixed, const uint8_t* plane, int pitch, int row, int col, const uint32_t* g, int gstride, int taps4, int (&res)[4]) {
+        constexpr int T = decltype(fixed)::value;                           // 0: any number of tap dwords (rolled loop)
         const uint32_t at = (uint32_t)(__mul24(row, pitch) + col);          // byte offset of the first row's window in the plane
         const uint32_t* w = (const uint32_t*)(plane + (at & ~3u));
         const uint32_t sh = (at & 3u) * 8u;
@@ -164,24 +169,50 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         const uint32_t* w1 = w + pw;
         const uint32_t* w2 = w1 + pw;
         const uint32_t* w3 = w2 + pw;
-        const uint32_t* gl = g;
-        const uint32_t* gh = g + __mul24(taps4, gstride);
-        int acc_l[4] = {0, 0, 0, 0}, acc_h[4] = {0, 0, 0, 0};
-        uint32_t cur[4] = {w[0], w1[0], w2[0], w3[0]};
-        for (int q = 0; q < taps4; q++) {
-            const int dl = (int)*gl, dh = (int)*gh;
-            gl += gstride; gh += gstride;
-            const uint32_t nxt[4] = {w[q + 1], w1[q + 1], w2[q + 1], w3[q + 1]};
+        int acc_l[4] = {128 << 14, 128 << 14, 128 << 14, 128 << 14}, acc_h[4] = {0, 0, 0, 0};
+        if constexpr (T > 0) {
+            uint32_t win[4][T + 1];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t sv = __builtin_amdgcn_alignbit(nxt[r], cur[r], sh) ^ 0x80808080u;
-                acc_l[r] = __builtin_amdgcn_sdot4(dl, (int)sv, acc_l[r], false);
-                acc_h[r] = __builtin_amdgcn_sdot4(dh, (int)sv, acc_h[r], false);
-                cur[r] = nxt[r];
+            for (int q = 0; q <= T; q++) { win[0][q] = w[q]; win[1][q] = w1[q]; win[2][q] = w2[q]; win[3][q] = w3[q]; }
+#pragma unroll
+            for (int q = 0; q < T; q++) {
+                const int dl = (int)g[q * gstride], dh = (int)g[(T + q) * gstride];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t sv = __builtin_amdgcn_alignbit(win[r][q + 1], win[r][q], sh) ^ 0x80808080u;
+                    acc_l[r] = __builtin_amdgcn_sdot4(dl, (int)sv, acc_l[r], false);
+                    acc_h[r] = __builtin_amdgcn_sdot4(dh, (int)sv, acc_h[r], false);
+                }
+            }
+        } else {
+            const uint32_t* gl = g;
+            const uint32_t* gh = g + __mul24(taps4, gstride);
+            uint32_t cur[4] = {w[0], w1[0], w2[0], w3[0]};
+            for (int q = 0; q < taps4; q++) {
+                const int dl = (int)*gl, dh = (int)*gh;
+                gl += gstride; gh += gstride;
+                const uint32_t nxt[4] = {w[q + 1], w1[q + 1], w2[q + 1], w3[q + 1]};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t sv = __builtin_amdgcn_alignbit(nxt[r], cur[r], sh) ^ 0x80808080u;
+                    acc_l[r] = __builtin_amdgcn_sdot4(dl, (int)sv, acc_l[r], false);
+                    acc_h[r] = __builtin_amdgcn_sdot4(dh, (int)sv, acc_h[r], false);
+                    cur[r] = nxt[r];
+                }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) res[r] = (acc_h[r] << 8) + acc_l[r] + (128 << 14);
+        for (int r = 0; r < 4; r++) res[r] = (acc_h[r] << 8) + acc_l[r];
+    };
+    // calls `body` with the number of tap dwords as a compile-time constant when it is a common one
+    auto with_taps = [&](int taps4, auto body) {
+        switch (taps4) {
+            case 1: body(std::integral_constant<int, 1>{}); break;
+            case 2: body(std::integral_constant<int, 2>{}); break;
+            case 3: body(std::integral_constant<int, 3>{}); break;
+            case 4: body(std::integral_constant<int, 4>{}); break;
+            default: body(std::integral_constant<int, 0>{}); break;
+        }
     };
 
     int have_l = -(1 << 30), have_c = -(1 << 30);          // source rows below these are in the rings (luma / chroma stream)
@@ -331,39 +362,43 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         {
             const int rows = n1 - n0, c_off = -xa, taps4 = job.lh.taps4;
             const int ring0 = (n0 + offL) % ringL;
-            DivWalk la(tid, 256, tw);
-            for (int item = tid; item < ((rows + 3) >> 2) * tw; item += 256, la.next()) {
-                const int r4 = la.q * 4, i = la.r;
-                int acc[4];
-                hpass4(p0, rcols, r4, l_lh[i] + c_off, g_lh + i, TW, taps4, acc);
-                int rr = ring0 + r4;
-                if (rr >= ringL) rr -= ringL;
+            with_taps(taps4, [&](auto fixed) {
+                DivWalk la(tid, 256, tw);
+                for (int item = tid; item < ((rows + 3) >> 2) * tw; item += 256, la.next()) {
+                    const int r4 = la.q * 4, i = la.r;
+                    int acc[4];
+                    hpass4(fixed, p0, rcols, r4, l_lh[i] + c_off, g_lh + i, TW, taps4, acc);
+                    int rr = ring0 + r4;
+                    if (rr >= ringL) rr -= ringL;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int t = clampi(acc[r] >> 7, 0, 32767);
-                    if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
-                    if (r4 + r < rows) tmpL[__mul24(rr, TW) + i] = (int16_t)t;
-                    rr = rr + 1 == ringL ? 0 : rr + 1;
+                    for (int r = 0; r < 4; r++) {
+                        int t = clampi(acc[r] >> 7, 0, 32767);
+                        if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
+                        if (r4 + r < rows) tmpL[__mul24(rr, TW) + i] = (int16_t)t;
+                        rr = rr + 1 == ringL ? 0 : rr + 1;
+                    }
                 }
-            }
+            });
             const int crows = cn1 - cn0, cc_off = FMT == 0 ? -xa : -cxa4, ctaps4 = job.ch.taps4;
             const int cring0 = (cn0 + offC) % ringC;
             const int cgroups = (crows + 3) >> 2;
-            DivWalk ca(tid, 256, cw);
-            for (int item = tid; item < 2 * cgroups * cw; item += 256, ca.next()) {
-                const int comp = ca.q >= cgroups ? 1 : 0, r4 = (ca.q - comp * cgroups) * 4, i = ca.r;      // groups 0..cgroups-1: Cr, then Cb
-                int acc[4];
-                hpass4(comp ? p1 : p2, crcols, r4, l_ch[i] + cc_off, g_ch + i, CW, ctaps4, acc);      // comp 0 = Cr, 1 = Cb
-                int rr = cring0 + r4;
-                if (rr >= ringC) rr -= ringC;
+            with_taps(ctaps4, [&](auto fixed) {
+                DivWalk ca(tid, 256, cw);
+                for (int item = tid; item < 2 * cgroups * cw; item += 256, ca.next()) {
+                    const int comp = ca.q >= cgroups ? 1 : 0, r4 = (ca.q - comp * cgroups) * 4, i = ca.r;      // groups 0..cgroups-1: Cr, then Cb
+                    int acc[4];
+                    hpass4(fixed, comp ? p1 : p2, crcols, r4, l_ch[i] + cc_off, g_ch + i, CW, ctaps4, acc);      // comp 0 = Cr, 1 = Cb
+                    int rr = cring0 + r4;
+                    if (rr >= ringC) rr -= ringC;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int t = clampi(acc[r] >> 7, 0, 32767);
-                    if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
-                    if (r4 + r < crows) tmpC[__mul24(__mul24(comp, ringC) + rr, CW) + i] = (int16_t)t;
-                    rr = rr + 1 == ringC ? 0 : rr + 1;
+                    for (int r = 0; r < 4; r++) {
+                        int t = clampi(acc[r] >> 7, 0, 32767);
+                        if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
+                        if (r4 + r < crows) tmpC[__mul24(__mul24(comp, ringC) + rr, CW) + i] = (int16_t)t;
+                        rr = rr + 1 == ringC ? 0 : rr + 1;
+                    }
                 }
-            }
+            });
         }
         __syncthreads();
 
