@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         int t = clampi(acc[r] >> 7, 0, 32767);
-                        if (job.limited) t = (int)(((long long)min(t, 30189) * 19077 - 39057361) >> 14);
+                        if (job.limited) t = (__mul24(min(t, 30189), 19077) - 39057361) >> 14;        // (at most 30189 * 19077 < 2^31)
                         if (r4 + r < rows) tmpL[__mul24(rr, TW) + i] = (int16_t)t;
                         rr = rr + 1 == ringL ? 0 : rr + 1;
                     }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         int t = clampi(acc[r] >> 7, 0, 32767);
-                        if (job.limited) t = (int)(((long long)min(t, 30775) * 4663 - 9289992) >> 12);
+                        if (job.limited) t = (__mul24(min(t, 30775), 4663) - 9289992) >> 12;
                         if (r4 + r < crows) tmpC[__mul24(__mul24(comp, ringC) + rr, CW) + i] = (int16_t)t;
                         rr = rr + 1 == ringC ? 0 : rr + 1;
                     }
