@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -404,14 +405,22 @@ extern "C" int psxhip_str_encode_host(psxhip_str_ctx_t* c, const psxhip_str_sett
                                                 s->video_height, pl.pub.max_frame_size);
             if (rc_video == PSXHIP_OK) memcpy(c->key, key, sizeof key);
         }
+        const auto tv0 = std::chrono::steady_clock::now();
         if (rc_video == PSXHIP_OK)
             rc_video = psxhip_mdec_multi_encode_frames_host(c->mdec, frames, nf, pl.budgets.data(), 0, bs, ostride, res.data(),
                                                             PSXHIP_SCHED_STATIC, 0, nullptr);
         if (rc_video) snprintf(err_video, sizeof err_video, "%s", psxhip_last_error());     // thread-local text
-        else build_all(true);
+        else {
+            const auto tv1 = std::chrono::steady_clock::now();
+            build_all(true);
+            if (getenv("PSXHIP_STR_TRACE"))
+                fprintf(stderr, "psxhip_str: video encode %.3f ms, video sectors %.3f ms\n", std::chrono::duration<double, std::milli>(tv1 - tv0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv1).count());
+        }
     });
 
     // ---- audio: one XA stream, concurrently (on the list's first device: 3 ms of work next to the frames')
+    const auto ta0 = std::chrono::steady_clock::now();
     const int ch = s->audio_channels;
     int na = 0;
     for (const Sector& sc : pl.sectors) na += sc.frame == -1;
@@ -441,7 +450,11 @@ extern "C" int psxhip_str_encode_host(psxhip_str_ctx_t* c, const psxhip_str_sett
                                                        &lba0, st, xa_out.data(), (int64_t)xa_out.size(), 0, eof.data());
         if (rc_audio > 0) rc_audio = rc_audio == (int)(na * ssz) ? PSXHIP_OK : PSXHIP_EINVAL;
     }
+    const auto ta1 = std::chrono::steady_clock::now();
     if (rc_audio == PSXHIP_OK) build_all(false);
+    if (getenv("PSXHIP_STR_TRACE"))
+        fprintf(stderr, "psxhip_str: audio encode done at %.3f ms after entry to the audio leg, audio sectors %.3f ms\n",
+                std::chrono::duration<double, std::milli>(ta1 - ta0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta1).count());
     video.join();
     if (rc_video) {
         psxhip_set_error("psxhip_str_encode_host: video: %s", err_video);
