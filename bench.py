@@ -484,6 +484,37 @@ def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
                                             "kernel_ms_min": round(cold[0], 5), "kernel_ms_max": round(cold[-1], 5), "contexts": len(cold)}
     except Exception as e:          # secondary figures never fail the bench line
         out["error"] = repr(e)
+    # The frames of the headline are already NV21 in HBM.  Where they come from decoded pictures, the colour-conversion / scaling
+    # front-end (psxhip_scaler_*; own arithmetic, parity with libswscale unpinned) makes them on the device: its
+    # rate alone and in a chain with the encoder on one stream (320x240 targets only).
+    try:
+        if (w, h) == (320, 240) and args.codec == 0:
+            from psxavenc_amd.frontend import Scaler
+            sc = Scaler(0, 640, 480, w, h, device=local_rank)
+            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+            d_src = torch.randint(0, 256, (n, sc.source_bytes), dtype=torch.uint8, device=dev)
+            d_frames = torch.empty((n, sc.frame_bytes), dtype=torch.uint8, device=dev)
+
+            def chain(reps, with_encoder):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    sc.convert_device(d_src, d_frames)
+                    if with_encoder:
+                        enc.encode_frames_device(d_frames, budget, d_out=d_out, d_results=d_res)
+                b.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+
+            chain(3, True)
+            ms_sc, ms_chain = chain(20, False), chain(20, True)
+            out["pictures_to_bs_chain"] = {"source": "rgb24 640x480 (random pictures, resident in HBM)", "scaler_pictures_per_sec": round(n / ms_sc * 1e3, 1),
+                                           "scaler_algorithmic_gbs": round((sc.source_bytes + sc.frame_bytes) * n / ms_sc / 1e6, 1),
+                                           "chain_frames_per_sec": round(n / ms_chain * 1e3, 1), "parity": "front-end unpinned (libswscale absent)"}
+            enc.close()
+            sc.close()
+    except Exception as e:
+        out["pictures_to_bs_chain"] = {"error": repr(e)}
     return out
 
 
