@@ -144,10 +144,11 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
         xa = min(lxa, cxa) & ~3; xb = (max(lxb, cxb) + 3) & ~3;
         rcols = xb - xa; crcols = rcols;
     } else {
-        xa = lxa & ~3; xb = (lxb + 3) & ~3;
+        // (YUV planes are staged sixteen bytes to a lane: regions start and end on multiples of sixteen samples)
+        xa = lxa & ~15; xb = (lxb + 15) & ~15;
         rcols = xb - xa;
-        cxa4 = cxa & ~3;
-        crcols = ((cxb + 3) & ~3) - cxa4;
+        cxa4 = cxa & ~15;
+        crcols = ((cxb + 15) & ~15) - cxa4;
     }
     // ring position of source row r (r may be negative: edge replication reaches above the picture)
     const int offL = ringL * 128, offC = ringC * 128;
@@ -318,36 +319,41 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
             const uint8_t* Y = src;
             const uint8_t* U = src + (size_t)job.sw * job.sh;
             const uint8_t* V = U + (size_t)job.csw * job.csh;
+            // a lane moves sixteen samples: one 16-byte load (the picture's rows need not be 16-byte aligned; the loads are dword
+            // aligned), one 16-byte LDS store (the planes' rows are).  The first version moved dwords: 25 instructions per dword
+            // made this plain copy 38 % of the kernel.
             auto stage = [&](uint8_t* dst, const uint8_t* plane, int pw, int ph, int y0, int rows, int x0, int cols) {
-                const int groups = cols >> 2, n_items = rows * groups;
+                const int groups = cols >> 4, n_items = rows * groups;
                 const bool aligned = (pw & 3) == 0 && (((uintptr_t)plane) & 3) == 0;
-                constexpr int kU = 8;
+                constexpr int kU = 2;
                 DivWalk at(tid, 256, groups);
                 for (int base = tid; base < n_items; base += 256 * kU) {
-                    uint32_t v[kU];
+                    uint4 v[kU];
 #pragma unroll
                     for (int u = 0; u < kU; u++) {
                         const int item = base + u * 256;
-                        if (item - tid >= n_items) break;         // (uniform: no lane has an item in this slot or the ones after)
                         const int r = at.q, g = at.r;
                         at.next();
-                        const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 4 * g;
+                        const int sy = clampi(y0 + r, 0, ph - 1), x = x0 + 16 * g;
                         const uint32_t rowoff = __umul24((uint32_t)sy, (uint32_t)pw);      // (planes are at most 16384 x 16384)
-                        v[u] = 0u;
+                        v[u] = make_uint4(0u, 0u, 0u, 0u);
                         if (item < n_items) {
-                            if (aligned && x >= 0 && x + 3 < pw) {
-                                v[u] = *(const uint32_t*)(plane + (rowoff + (uint32_t)x));
-                            } else {
+                            if (aligned && x >= 0 && x + 15 < pw) {
+                                __builtin_memcpy(&v[u], plane + (rowoff + (uint32_t)x), 16);
+                            } else {                          // the picture's edges: clamped coordinates, byte by byte
+                                auto four = [&](int xk) {
+                                    uint32_t d = 0u;
 #pragma unroll
-                                for (int k = 0; k < 4; k++) v[u] |= (uint32_t)plane[rowoff + (uint32_t)clampi(x + k, 0, pw - 1)] << (8 * k);
+                                    for (int k = 0; k < 4; k++) d |= (uint32_t)plane[rowoff + (uint32_t)clampi(xk + k, 0, pw - 1)] << (8 * k);
+                                    return d;
+                                };
+                                v[u] = make_uint4(four(x), four(x + 4), four(x + 8), four(x + 12));
                             }
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < kU; u++) {
-                        if (base - tid + u * 256 >= n_items) break;
-                        if (base + u * 256 < n_items) ((uint32_t*)dst)[base + u * 256] = v[u];
-                    }
+                    for (int u = 0; u < kU; u++)
+                        if (base + u * 256 < n_items) ((uint4*)dst)[base + u * 256] = v[u];
                 }
             };
             stage(p0, Y, job.sw, job.sh, n0, n1 - n0, xa, rcols);
@@ -604,12 +610,12 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
         reach(s->h[3], dst_height / 2, TH / 2, nullptr, &cr);
         int reg_rows, reg_cols, creg_rows, creg_cols;
         if (yuv) {
-            // every plane's region starts and ends on a multiple of four samples (a lane stages whole dwords)
+            // every plane's region starts and ends on a multiple of sixteen samples (a lane stages sixteen bytes)
             auto reach4 = [](const HostBank& b, int n, int tile) {
                 int best = 0;
                 for (int a = 0; a < n; a += tile) {
                     const int e = (a + tile < n ? a + tile : n) - 1;
-                    const int lo = b.left[(size_t)a] & ~3, hi = (b.left[(size_t)e] + b.taps + 3) & ~3;
+                    const int lo = b.left[(size_t)a] & ~15, hi = (b.left[(size_t)e] + b.taps + 15) & ~15;
                     if (hi - lo > best) best = hi - lo;
                 }
                 return best;
