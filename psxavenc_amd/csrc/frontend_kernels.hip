@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     // the vertical tables of a tile, two copies taken in turn (a tile's are loaded while the previous tile's are still read)
     int32_t* v_tab = l_ch + CW;
     const int v_words = TH + CH + (TH * job.lv.taps + CH * job.cv.taps + 1) / 2;
+    // the source rows every tile of this segment reaches (first and past-the-last row of its luma / chroma taps): looked up once
+    // for the walk -- as four scalar loads at the top of every tile they stalled the whole workgroup for a memory round trip
+    int32_t* t_rows = v_tab + 2 * v_words;                                       // [tiles of the segment][4]
 
     // (transposed on the way in: dword q of output column i at [q][i], so that the lanes of a wavefront -- consecutive columns --
     //  read consecutive dwords; column-major rows of 4 dwords put every eighth lane on the same LDS bank)
@@ -137,6 +140,14 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     }
     if (tid < tw) l_lh[tid] = job.lh.left[X0 + tid];
     if (tid < cw) l_ch[tid] = job.ch.left[cX0 + tid];
+    for (int t = tid; t < ty1 - ty0; t += 256) {
+        const int Y0 = (ty0 + t) * TH, Y1 = min(job.dh, Y0 + TH), cY0 = Y0 >> 1, chh = (Y1 - Y0) >> 1;
+        t_rows[4 * t + 0] = job.lv.left[Y0];
+        t_rows[4 * t + 1] = job.lv.left[Y1 - 1] + job.lv.taps;
+        t_rows[4 * t + 2] = job.cv.left[cY0];
+        t_rows[4 * t + 3] = job.cv.left[cY0 + chh - 1] + job.cv.taps;
+    }
+    __syncthreads();
 
     // the staged columns (whole groups of four samples: a lane moves dwords)
     int xa, xb, rcols, crcols, cxa4 = 0;
@@ -220,8 +231,8 @@ __global__ __launch_bounds__(256) void scaler_kernel(const ScalerJob job) {
     for (int ty = ty0; ty < ty1; ty++) {
         const int Y0 = ty * TH, Y1 = min(job.dh, Y0 + TH);
         const int th = Y1 - Y0, chh = th >> 1, cY0 = Y0 >> 1;
-        const int lya = job.lv.left[Y0], lyb = job.lv.left[Y1 - 1] + job.lv.taps;
-        const int cya = job.cv.left[cY0], cyb = job.cv.left[cY0 + chh - 1] + job.cv.taps;
+        const int lya = t_rows[4 * (ty - ty0) + 0], lyb = t_rows[4 * (ty - ty0) + 1];
+        const int cya = t_rows[4 * (ty - ty0) + 2], cyb = t_rows[4 * (ty - ty0) + 3];
         int32_t* vt = v_tab + ((ty - ty0) & 1) * v_words;
         int32_t* l_lv = vt;                                   // [TH] ring position of the first tap's row
         int32_t* l_cv = l_lv + TH;                            // [CH]
@@ -646,7 +657,7 @@ extern "C" int psxhip_scaler_create(psxhip_scaler_t** out, int device, int src_f
         const size_t crows_cap = yuv ? (size_t)creg_rows : (size_t)reg_rows;
         const size_t v_words = (size_t)TH + TH / 2 + ((size_t)TH * s->h[1].taps + (size_t)(TH / 2) * s->h[3].taps + 1) / 2;      // one tile's vertical tables
         need = plane + 2 * cplane + 2 * ((size_t)reg_rows * TW + 2 * crows_cap * (TW / 2)) +
-               8 * ((size_t)TW * s->h[0].taps4 + (size_t)(TW / 2) * s->h[2].taps4) + 4 * ((size_t)TW + TW / 2) + 4 * 2 * v_words + 16;
+               8 * ((size_t)TW * s->h[0].taps4 + (size_t)(TW / 2) * s->h[2].taps4) + 4 * ((size_t)TW + TW / 2) + 4 * 2 * v_words + 16 * (((size_t)dst_height + TH - 1) / TH) + 16;
         if (need * 2 <= (size_t)prop.maxSharedMemoryPerMultiProcessor || (t == 3 && need <= (size_t)prop.maxSharedMemoryPerMultiProcessor)) {
             ok = true;
             j.TW = TW; j.TH = TH;
