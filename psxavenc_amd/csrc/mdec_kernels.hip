@@ -869,6 +869,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                 };
                 constexpr int kDcItems = 8;      // loads in flight per lane
+                // (diagnostics build only: bit 24 of the priority word runs the byte-sum read TWICE -- same results; the difference
+                //  between the two launches is what the read costs, i.e. what a v3 frame would gain if the DC terms came for free)
+                const int dc_reps = STATS && ((job.prio_pattern >> 24) & 1u) ? 2 : 1;
+                for (int rep = 0; rep < dc_reps; rep++)
                 for (int item = wid; item < total_items; item += kDcItems * kWavesPerGroup) {
                     bool ch[kDcItems], ok[kDcItems];
                     int R[kDcItems], c[kDcItems];
