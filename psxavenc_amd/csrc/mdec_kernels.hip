@@ -841,7 +841,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     R = it2 / gpr;
                     c = (it2 - R * gpr) * 8 + cl;
                     ok = item < total_items && c < cpr;
-                    return frame + ((chroma ? (uint32_t)W * (uint32_t)H : 0u) + (uint32_t)(R * 8 + r) * (uint32_t)W + (uint32_t)c * 16u);
+                    // (a lane without an item reads the frame's first bytes -- every lane loads, nothing sits under a branch -- and
+                    //  its sums are not stored)
+                    return frame + (ok ? (chroma ? (uint32_t)W * (uint32_t)H : 0u) + __umul24((uint32_t)(R * 8 + r), (uint32_t)W) + (uint32_t)c * 16u : 0u);
                 };
                 auto item_sums = [&](const uint4& v, bool chroma, int R, int c, bool ok) {
                     int s0, s1;
@@ -880,8 +882,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
 #pragma unroll
                     for (int u = 0; u < kDcItems; u++) {
                         const uint8_t* pp = item_addr(item + u * kWavesPerGroup, ch[u], R[u], c[u], ok[u]);
-                        v[u] = make_uint4(0, 0, 0, 0);
-                        if (ok[u]) v[u] = *(const uint4*)pp;
+                        v[u] = *(const uint4*)pp;
                     }
 #pragma unroll
                     for (int u = 0; u < kDcItems; u++) item_sums(v[u], ch[u], R[u], c[u], ok[u]);
