@@ -463,6 +463,34 @@ def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
         torch.cuda.synchronize()
         return a.elapsed_time(b) / launches
 
+    # The headline launches are in order on one stream: a launch's tail (a CU here and there still finishing its second frame) is
+    # not filled by the next launch's head.  Two contexts on two streams -- what a caller with independent batches can do -- are.
+    try:
+        encs = [MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank) for _ in range(2)]
+        strs = [torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)]
+        outs = [(d_out, d_res), (torch.zeros_like(d_out), torch.zeros_like(d_res))]
+        b4 = [synth.frames_device(w, h, args.seed + 300 + b, first, n, args.amp, device=local_rank) for b in range(4)]
+
+        def both(launches):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(strs[0])
+            strs[1].wait_stream(strs[0])
+            for k in range(launches):
+                i = k & 1
+                encs[i].encode_frames_device(b4[k % 4], budget, d_out=outs[i][0], d_results=outs[i][1], stream=strs[i])
+            strs[0].wait_stream(strs[1])
+            b.record(strs[0])
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / launches
+
+        both(16)
+        ms2 = min(both(400), both(400))
+        out["two_contexts_two_streams"] = {"frames_per_sec": round(n / ms2 * 1e3, 1), "ms_per_launch": round(ms2, 5), "launches": 400}
+        for e in encs:
+            e.close()
+    except Exception as e:
+        out["two_contexts_two_streams"] = {"error": repr(e)}
     try:
         enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
         b8 = [synth.frames_device(w, h, args.seed + 100 + b, first, n, 8, device=local_rank) for b in range(4)]

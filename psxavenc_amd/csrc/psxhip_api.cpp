@@ -235,8 +235,9 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
         HIP_TRY(hipMalloc((void**)&c->d_retry, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_ENOMEM);
         HIP_TRY(hipMemset(c->d_retry, 0xFF, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_EDEVICE);
     }
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    // (the host path's two streams are created when it is first used: a context that only ever launches on its caller's streams
+    //  would otherwise take two of the device's few hardware queues -- streams are dealt onto them round-robin -- and with three
+    //  contexts alive two callers' streams shared one queue: their launches ran one after the other)
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->kernel_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
     c->n_cu = prop.multiProcessorCount;
     // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
@@ -457,6 +458,8 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
     if ((size_t)chunk * fsz > staging_cap) chunk = (int)(staging_cap / fsz);
     if (chunk < 1) chunk = 1;
     if (chunk > n_frames) chunk = n_frames;
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+    if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), PSXHIP_EDEVICE);
     if (chunk > c->cap_frames || dstride > c->cap_out_stride) {
         const int cap = chunk > c->cap_frames ? chunk : c->cap_frames;
         const size_t os = dstride > c->cap_out_stride ? dstride : c->cap_out_stride;
