@@ -61,15 +61,40 @@ def _init_dist(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        # --force-dist: a world-size-1 group, so that the RCCL leg (init with device_id, barrier(device_ids), all_gather of
+        # device tensors) runs on the one GPU a dev box has before an 8-GPU node runs it for the first time
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a rank that dies must not leave the others in a collective for ever: they fail after this and report it (see _report_failure)
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=tmo)
     xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # where the tiny exchange tensors live
     return rank, world, local_rank, dev, dist, xdev
+
+
+def _dist_info(args, dist):
+    """what carried the barriers and the gathers of this run (None: a single process without a process group)"""
+    if dist is None:
+        return None
+    import torch
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "exchange_tensors_on": "device" if args.dist_backend == "nccl" else "host",
+            "forced_at_world_size_1": bool(args.force_dist and dist.get_world_size() == 1)}
+    try:
+        info["nccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.dist_backend == "nccl" else None
+    except Exception:
+        pass
+    return info
 
 
 def _barrier(args, dist, local_rank):
@@ -213,7 +238,30 @@ PRESETS = {
 }
 
 
+def _report_failure(exc):
+    """One JSON line instead of (in front of) a traceback: whichever rank fails says so on stdout -- the driver keeps the tail of
+    stdout -- and exits non-zero; the other ranks run into the collective's timeout (--dist-timeout) and report that."""
+    import traceback
+    tb = traceback.format_exc().strip().splitlines()
+    line = {"error": "%s: %s" % (type(exc).__name__, exc), "rank": int(os.environ.get("RANK", "0")),
+            "world_size": int(os.environ.get("WORLD_SIZE", "1")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+            "where": tb[-3:] if len(tb) >= 3 else tb, "argv": sys.argv[1:]}
+    print(json.dumps(line), flush=True)
+
+
 def main():
+    try:
+        return _main()
+    except SystemExit as e:
+        if e.code not in (0, None) and not isinstance(e.code, int):
+            _report_failure(e)
+        raise
+    except BaseException as e:      # noqa: BLE001 -- the line is the point
+        _report_failure(e)
+        sys.exit(1)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -224,7 +272,7 @@ def main():
                          "8 channels x 60 min).  Explicit flags below override a preset's values")
     ap.add_argument("--launches-per-step", type=int, default=0,
                     help="a step = this many back-to-back launches, cycling over --batches distinct batches (default: enough for "
-                         "--steps steps to time well over a second of GPU work: 400 launches of 1000 320x240 frames)")
+                         "--steps 20 to time over ten seconds of GPU work: 3400 launches of 1000 320x240 frames)")
     ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
     ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
@@ -246,6 +294,17 @@ def main():
     ap.add_argument("--xa-channels", type=int, default=None)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing: several ranks may share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even with one rank (world size 1): runs the RCCL leg -- init_process_group('nccl', device_id), "
+                         "barrier(device_ids), device all_gather -- on a one-GPU box")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a collective waits for a rank that has died before the others report failure")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="sbs: launch lanes of the encoder context (psxhip_mdec_set_lanes): 1 = every launch ordered on the caller's stream behind "
+                         "the one before; 2 (the headline's default) = consecutive launches of the ONE context on the ONE caller stream may overlap "
+                         "(inputs ordered on the stream, results ordered by the next call or psxhip_mdec_fence)")
+    ap.add_argument("--no-config-secondaries", action="store_true",
+                    help="default run only: skip the other BASELINE configs (sbs_v3 share, xacd, strcd) and the RCCL world-size-1 self-test that "
+                         "are run as subprocesses after the timed region")
     args = ap.parse_args()
     preset = dict(PRESETS[args.config or "sbs_v2"])
     if args.workload and args.workload != preset["workload"]:          # --workload alone keeps its round-2 meaning
@@ -285,8 +344,8 @@ def main():
     fsz = w * h * 3 // 2
     nb = max(1, args.batches)
     lps = args.launches_per_step
-    if lps <= 0:        # >= ~60 ms of GPU work per step at the measured rates, so that 20 steps time > 1 s
-        lps = max(nb, min(400, int(round(400 * (1000 * 115200) / float(max(n, 1) * fsz)))))
+    if lps <= 0:        # >= ~0.5 s of GPU work per step at the measured rates: 20 steps time > 10 s (a 5-second utilisation sampler cannot miss it)
+        lps = max(nb, min(3400, int(round(3400 * (1000 * 115200) / float(max(n, 1) * fsz)))))
     ns = max(1, args.streams)
     encs = [MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank) for _ in range(ns)]
     enc = encs[0]
@@ -371,6 +430,13 @@ def main():
             cpu_baseline = _cpu_baseline_mdec(args.codec, w, h, budget, args.amp, args.seed, args.cpu_seconds)
         if world == 1 and not args.no_secondary and ns == 1:
             secondary = _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first)
+            if torch.cuda.device_count() > 1:
+                secondary["c_abi_device_list"] = _secondary_device_list(args, torch, w, h, budget, d_batches)
+            if args.config == "sbs_v2" and not args.no_config_secondaries:
+                for e in encs:          # (the children get the GPU to themselves)
+                    e.close()
+                encs = []
+                secondary.update(_secondary_configs(args))
 
     version = _lib.lib().psxhip_version().decode()
     wl_key = "sbs codec=%d %dx%d budget=%d frames=%d amp=%d | %s" % (args.codec, w, h, budget, n, args.amp, version)
@@ -436,6 +502,7 @@ def main():
             "secondary": secondary,
             "parity": parity,
             "results_sane": all(bool(q[1]) for q in scale_sum),
+            "dist": _dist_info(args, dist),
         }
         print(json.dumps(line), flush=True)
     for e in encs:
@@ -546,6 +613,90 @@ def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
     return out
 
 
+def _secondary_device_list(args, torch, w, h, budget, d_batches):
+    """More than one GPU visible to a single-process run: the C-ABI's own sharding (psxhip_multi.cpp: one host thread, encoder
+    context and pinned staging pair per listed device; the reference's host side is one C loop, filefmt.c:633-662, it has no
+    ranks) over ALL visible devices, host buffers in and out, every byte compared with device 0 alone."""
+    import numpy as np
+    try:
+        from psxavenc_amd.mdec import MdecEncoder
+        from psxavenc_amd.multi import MdecMulti, SCHED_STATIC, SCHED_TICKETS
+        devs = list(range(torch.cuda.device_count()))
+        frames = np.concatenate([b.cpu().numpy() for b in d_batches], axis=0)
+        n = frames.shape[0]
+        one = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=0)
+        want, want_res = one.encode_frames_host(frames, budget)
+        t0 = time.perf_counter()
+        one.encode_frames_host(frames, budget, out=want, res=want_res)
+        t_one = time.perf_counter() - t0
+        one.close()
+        out = {"devices": devs, "frames": int(n), "one_device_frames_per_sec": round(n / t_one, 1), "host_buffers": True}
+        m = MdecMulti(devs, args.codec, w, h, max_frame_size=budget)
+        for name, sched in (("static", SCHED_STATIC), ("tickets", SCHED_TICKETS)):
+            got, got_res = m.encode_frames_host(frames, budget, schedule=sched)
+            t0 = time.perf_counter()
+            m.encode_frames_host(frames, budget, schedule=sched, out=got, res=got_res)
+            dt = time.perf_counter() - t0
+            out[name] = {"frames_per_sec": round(n / dt, 1), "bit_exact_vs_device_0": bool(np.array_equal(got, want) and np.array_equal(got_res, want_res)),
+                         "per_device": m.last_report}
+        m.close()
+        return out
+    except Exception as e:      # secondary figures never fail the bench line
+        return {"error": repr(e)}
+
+
+def _secondary_configs(args):
+    """The default run's other BASELINE configs, each as a child `python bench.py --config ...` after the headline's timed region
+    (its own process: own contexts, own HBM, a failure stays its own), timed > 0.5 s, with its parity sample and CPU baseline:
+    one GPU's share of config 4 (`sbs v3`, 1250 of the 10 000 frames), config 5 (`xacd`, all 540 000 sectors), config 3 (`strcd`).
+    And the RCCL leg at world size 1 under torch.distributed.run, exactly as the driver launches N ranks."""
+    import socket
+    import subprocess
+    me = os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    seed = ["--seed", str(args.seed)]
+    jobs = [
+        ("sbs_v3_1250", [sys.executable, me, "--config", "sbs_v3", "--total-frames", "1250", "--steps", "8", "--warmup", "2", "--no-secondary",
+                         "--cpu-seconds", "4"] + seed),
+        ("xacd_config5", [sys.executable, me, "--config", "xacd", "--steps", "20", "--warmup", "2", "--cpu-seconds", "5"] + seed),
+        ("strcd_config3", [sys.executable, me, "--config", "strcd", "--steps", "150", "--warmup", "5", "--cpu-seconds", "4"] + seed),
+        ("rccl_world_size_1", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port), me, "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2", "--warmup", "1",
+                               "--launches-per-step", "200", "--no-secondary", "--no-cpu-baseline"] + seed),
+    ]
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "timed_region_s", "scaling", "config", "roofline", "cpu_baseline", "parity",
+            "dist", "error")
+    out = {}
+    for name, cmd in jobs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            line = None
+            for ln in reversed(r.stdout.strip().splitlines()):
+                if ln.startswith("{"):
+                    try:
+                        line = json.loads(ln)
+                        break
+                    except Exception:
+                        pass
+            if line is None:
+                out[name] = {"error": "no JSON line", "rc": r.returncode, "stderr_tail": r.stderr.strip().splitlines()[-3:]}
+            else:
+                out[name] = {k: line[k] for k in keep if k in line}
+                out[name]["rc"] = r.returncode
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[name]["cmd"] = " ".join(cmd[1:] if cmd[1] != "-m" else cmd[1:])
+    return out
+
+
 def bench_xacd(args):
     """Config 'xacd': 8 XA channels x stereo, 37800 Hz, 4-bit -> 2352-byte sectors.  16 serial chains; parallelism comes
     from speculate-and-verify along time (psxhip_adpcm_session_*), and across GPUs from time-sharding with a final-state
@@ -624,8 +775,8 @@ def bench_xacd(args):
         alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
         print(json.dumps({
             "metric": "xa_37800_4bit_stereo_sectors_per_sec", "value": round(value, 2), "unit": "sectors/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dist": _dist_info(args, dist),
             "config": {"workload": "xacd: %d XA channels x stereo x %.0f s @ 37800 Hz, 4-bit, %d sectors per channel, time-sharded x%d"
                                    % (n_ch, n_sectors * sps / 37800.0, n_sectors, world),
                        "preset": args.config, "baseline_config": args.baseline_config,
@@ -694,8 +845,8 @@ def bench_strcd(args):
         alg = (w * h * 3 // 2) * p2.n_frames_encoded + na * 4 + p.n_sectors * p.sector_size
         print(json.dumps({
             "metric": "strcd_v2_320x240_sectors_per_sec", "value": round(total / elapsed, 2), "unit": "sectors/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dist": _dist_info(args, dist),
             "config": {"workload": "strcd v2: %d frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA per GPU per step -> %d sectors of 2352 bytes "
                                    "(%d video, %d audio); host buffers in and out (PCIe + host interleave inside the timed region)"
                                    % (n, p.n_sectors, p.n_video_sectors, p.n_audio_sectors),

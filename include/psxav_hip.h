@@ -63,13 +63,51 @@ void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
  * NULL, then every frame uses uniform_max_size.  d_frames, d_out, frame_stride and out_stride
  * must be 4-byte aligned.  Asynchronous on `stream`; results land in d_results[i].
  * Launches on ONE context must be stream-ordered (same stream, or ordered by events): the context owns the
- * frame hand-out counters the kernel uses.  Use one context per concurrent stream.
+ * frame hand-out counters the kernel uses.  Use one context per concurrent stream (or two launch lanes, psxhip_mdec_set_lanes).
  * Per-frame budgets (device memory, not vetted by the host) outside [8, min(the context's max_frame_size,
  * out_stride)] make that frame's result quant_scale 64 and write nothing. */
 int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t *ctx, const uint8_t *d_frames, size_t frame_stride,
                                      int n_frames, const int32_t *d_frame_max_sizes, int uniform_max_size,
                                      uint8_t *d_out, size_t out_stride, psxhip_mdec_result_t *d_results,
                                      void *stream);
+
+/* Several batches, ONE launch.  The reference's caller is one in-order loop over frames (psxavenc/filefmt.c:641-647); a caller
+ * that holds a few batches -- four 1000-frame chunks of a file, say -- hands them over together and gets the behaviour of one
+ * large batch (frames of all batches are drawn from one ticket counter: no launch boundary between them, the tail of one batch
+ * is filled by the head of the next) without concatenating its buffers.  Bytes and results are those of one
+ * psxhip_mdec_encode_frames_device call per batch.  frame_stride, out_stride and uniform_max_size are common to the batches; a
+ * batch's d_frame_max_sizes may be NULL (uniform_max_size applies).  More than PSXHIP_MDEC_MAX_BATCHES batches are issued as
+ * several launches.  Batches with n_frames == 0 are skipped. */
+#define PSXHIP_MDEC_MAX_BATCHES 8
+typedef struct {
+	const uint8_t *d_frames;              /* n_frames NV21 frames, frame_stride apart */
+	int32_t n_frames;
+	int32_t reserved;
+	const int32_t *d_frame_max_sizes;     /* [n_frames] or NULL */
+	uint8_t *d_out;                       /* n_frames rows, out_stride apart */
+	psxhip_mdec_result_t *d_results;      /* [n_frames] */
+} psxhip_mdec_batch_t;
+int psxhip_mdec_encode_batches_device(psxhip_mdec_ctx_t *ctx, const psxhip_mdec_batch_t *batches, int n_batches,
+                                      size_t frame_stride, int uniform_max_size, size_t out_stride, void *stream);
+
+/* Launch lanes.  With one lane (the default) a launch is an ordinary stream operation: it starts when everything before it on
+ * `stream` is done, and everything after it on `stream` sees its results -- so consecutive launches of an in-order caller
+ * (filefmt.c:641-647 is one) run strictly one after the other, and the GPU idles through every launch's tail (8 % at 1000
+ * frames of 320x240: a launch ends when its slowest CU does).  With two lanes the context owns two sets of frame hand-out
+ * counters and two internal streams, and psxhip_mdec_encode_frames_device / _batches_device on a caller stream S become:
+ *   - INPUTS are stream-ordered: launch k starts when everything enqueued on S before call k is done;
+ *   - RESULTS lag one call: when call k returns, S is ordered behind launches 0 .. k-1; launch k itself is ordered into S by the
+ *     next encode call on the context or by psxhip_mdec_fence(ctx, S).  A caller that reads launch k's output (or reuses its
+ *     input or output buffers) must have called one of the two first -- i.e. it double-buffers, which is what lets the head of
+ *     launch k+1 fill the tail of launch k.
+ * Bytes never depend on the number of lanes.  lanes: 1 or 2.  Switching waits for the context's outstanding launches. */
+int psxhip_mdec_set_lanes(psxhip_mdec_ctx_t *ctx, int lanes);
+/* order `stream` behind every launch of the context issued so far (a no-op with one lane) */
+int psxhip_mdec_fence(psxhip_mdec_ctx_t *ctx, void *stream);
+/* Waits for the context's launches and returns, in *lost, how often the retry queue's watchdog gave a frame up (a workgroup that
+ * reserved a queue slot never filled it within about a second: a faulted or preempted workgroup).  0 on a healthy device --
+ * anything else means some launch's results are incomplete.  Never reset. */
+int psxhip_mdec_watchdog(psxhip_mdec_ctx_t *ctx, unsigned *lost);
 
 /* Same, host buffers: H2D, kernel, D2H, synchronise.  frame_max_sizes may be NULL (uniform).
  * Returns PSXHIP_ENOFIT if any frame could not be fitted (its result has quant_scale 64).

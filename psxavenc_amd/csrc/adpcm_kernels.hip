@@ -713,6 +713,8 @@ struct psxhip_adpcm_session {
     hipStream_t stream;
     ChunkJob job;
     DevMem d_chains, d_base, d_sbase, d_cchain, d_cfirst, d_ustates, d_used, d_cstates, d_lead, d_final, d_known, d_flags;
+    int* h_flags = nullptr;     // page-locked: the verify passes' "changed" words travel back through it (a session's runs are serialised)
+    ~psxhip_adpcm_session() { if (h_flags) (void)hipHostFree(h_flags); }
 };
 
 #define TRY(expr)                                                                                   \
@@ -846,9 +848,9 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
         // "some chunk's start state changed" is one word of device memory per pass.  Passes are launched in batches, back to
         // back: pass i + 1 looks at pass i's word when it starts and returns at once if nothing changed, so the host reads the
         // words once per batch -- no synchronise + launch round trip (40-50 us) per pass.  The words travel back through a
-        // page-locked buffer of the calling thread (a run is synchronous).
+        // page-locked buffer of the session (a run is synchronous).
         constexpr int kBatchMax = 16;
-        static thread_local int* h_flags = nullptr;
+        int*& h_flags = s->h_flags;      // owned by the session (a buffer per calling thread leaked one per worker thread of the multi-device calls)
         if (!h_flags && hipHostMalloc((void**)&h_flags, kBatchMax * sizeof(int), hipHostMallocDefault) != hipSuccess) {
             h_flags = nullptr;
             psxhip_set_error("adpcm_session_run: no page-locked memory for the verify flags");

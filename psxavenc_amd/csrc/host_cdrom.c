@@ -4,6 +4,7 @@
  * own headers and EDC are produced on the GPU (adpcm_kernels.hip).  Table CRC (slicing-by-8) instead of the
  * reference's bit-serial loop (cdrom.c:30-41): same polynomial, same result.
  */
+#include <pthread.h>
 #include <string.h>
 
 #include "psxav_audio.h"
@@ -13,7 +14,7 @@ _Static_assert(sizeof(psx_cdrom_sector_mode2_t) == PSX_CDROM_SECTOR_SIZE, "mode 
 
 /* slicing-by-8: edc_table[k][b] = CRC of byte b followed by k zero bytes; eight table look-ups per 8 input bytes */
 static uint32_t edc_table[8][256];
-static int edc_table_ready;
+static pthread_once_t edc_table_once = PTHREAD_ONCE_INIT;     /* one writer, whoever calls first (the library is re-entrant per object) */
 
 static void edc_init(void) {
 	for (uint32_t i = 0; i < 256; i++) {
@@ -26,11 +27,10 @@ static void edc_init(void) {
 			const uint32_t v = edc_table[k - 1][i];
 			edc_table[k][i] = (v >> 8) ^ edc_table[0][v & 0xFF];
 		}
-	__atomic_store_n(&edc_table_ready, 1, __ATOMIC_RELEASE);
 }
 
 static uint32_t edc(const uint8_t *p, int n) {
-	if (!__atomic_load_n(&edc_table_ready, __ATOMIC_ACQUIRE)) edc_init();
+	(void)pthread_once(&edc_table_once, edc_init);
 	uint32_t v = 0;
 	while (n >= 8) {
 		uint32_t lo, hi;

@@ -32,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "bs_vlc_lut.h"
 #include "mdec_search.h"
@@ -72,16 +73,25 @@ __constant__ uint8_t c_quant_zz[64];
 __constant__ uint8_t c_dc_prefix[2][8];   // [0] chroma, [1] luma
 __constant__ uint8_t c_dc_plen[2][8];
 
-struct FrameJob {
+// One launch encodes the frames of up to kMaxBatches batches (include/psxav_hip.h: psxhip_mdec_encode_batches_device): frame f of the
+// launch is frame f - first of the last batch whose `first` is <= f.  The table travels in the kernel arguments.
+constexpr int kMaxBatches = PSXHIP_MDEC_MAX_BATCHES;
+struct BatchDesc {
     const uint8_t* frames;
+    uint8_t* out;
+    psxhip_mdec_result_t* results;
+    const int32_t* max_sizes;      // per-frame budgets of this batch, or NULL (the launch's uniform budget)
+    int first;                     // index of the batch's first frame in the launch
+    int reserved;
+};
+struct FrameJob {
+    BatchDesc batch[kMaxBatches];
+    int n_batches;
     size_t frame_stride;
     int width, height, nx, ny, nmb;
-    int n_frames;
-    const int32_t* max_sizes;
+    int n_frames;                  // over all batches
     int uniform_max_size;
-    uint8_t* out;
     size_t out_stride;
-    psxhip_mdec_result_t* results;
     int out_words;           // LDS dwords reserved for the frame image tile (out_tile + 2)
     int out_tile;            // dwords of the frame image assembled in LDS at a time
     int max_frame_size;      // the context's largest budget
@@ -89,7 +99,8 @@ struct FrameJob {
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
     const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
-    unsigned int* ticket;    // [128]: [1] workgroups finished (self-resetting), [2] answer | budget << 8 of the previous launch's last frame (a hint that survives launches), [64..65] frame tickets + the retry queue's state, one 64-bit word, [96] groups started (self-resetting)
+    unsigned int* ticket;    // [128] of this launch's LANE: [1] workgroups finished (self-resetting), [3] frames lost by the retry queue's watchdog (never reset; psxhip_mdec_watchdog), [64..65] frame tickets + the retry queue's state, one 64-bit word, [96] groups started (self-resetting)
+    unsigned int* hint;      // one word shared by the context's lanes: answer | budget << 8 of the last frame (by index) of the launch that wrote it last -- a hint that survives launches
     unsigned int* retry;     // [retry_cap] retry queue: frame | scale to start from << 24, kRetryEmpty when vacant (NULL: frames are never handed on)
     int retry_patience;      // looks (about 3 us each) a group without work waits for a frame to be handed on
     int retry_cap;
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
     const uint8_t pro_plen = c_dc_plen[(tid >> 3) & 1][tid & 7], pro_prefix = c_dc_prefix[(tid >> 3) & 1][tid & 7];
     const uint8_t pro_qzz = c_quant_zz[tid & 63], pro_zagzig = c_zagzig[tid & 63];
-    const unsigned pro_shared_hint = job.ticket[2];
+    const unsigned pro_shared_hint = *job.hint;
 #pragma unroll
     for (int j = 0; j < kLutTrips; j++) {
         const int i = tid + j * kThreads;
@@ -783,11 +794,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
                 int got = -1;
                 if (there) {
+                    // The slot is filled right after it was reserved: the pusher sits between two adjacent atomics, and it is resident
+                    // (it pushes from inside its frame loop).  Should it never come -- a faulted or preempted pusher -- the wait ends
+                    // after about a second with the frame LOST: the slot is left to the pusher as "abandoned" (which then keeps its
+                    // frame, see hand_on) or, if it was filled at the last moment, taken; a word of the lane counts the watchdog's
+                    // bites for the host (psxhip_mdec_watchdog: non-zero = results of that launch are incomplete).
                     unsigned v = kRetryEmpty;
-                    for (int looks = 0; v == kRetryEmpty; looks++) v = queue_peek(&job.retry[h], looks);     // (filled right after it was reserved)
-                    L.scalars[S_FRAME] = (int)(v & 0xFFFFFFu);
-                    got = (int)(v >> 24);
-                    job.retry[h] = kRetryEmpty;          // vacated for the next launch (nobody looks at it again in this one)
+                    for (int looks = 0; v == kRetryEmpty && looks < (1 << 20); looks++) {
+                        v = queue_peek(&job.retry[h], looks);
+                        if (looks >= 4096) __builtin_amdgcn_s_sleep(32);
+                    }
+                    if (v == kRetryEmpty) {
+                        v = atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned);
+                        if (v == kRetryEmpty) { atomicAdd(&job.ticket[3], 1u); atomicAdd(&job.ticket[1], 0x10000u); }
+                    }
+                    if (v != kRetryEmpty) {
+                        L.scalars[S_FRAME] = (int)(v & 0xFFFFFFu);
+                        got = (int)(v >> 24);
+                        job.retry[h] = kRetryEmpty;          // vacated for the next launch (nobody looks at it again in this one)
+                    }
                 }
                 L.scalars[S_RETRY] = got;
             }
@@ -809,8 +834,26 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         lc.below = (1ull << lane) - 1ull;
         lc.lane_m64 = lane - 64;
         lc.zsrc = (int)L.tab_nat[lane];
-        const uint8_t* frame = job.frames + (size_t)f * job.frame_stride;
-        int max_size = job.max_sizes ? job.max_sizes[f] : job.uniform_max_size;
+        // which batch the frame belongs to (wave-uniform: f comes from one LDS word; scalar selects over the kernel arguments).
+        // Looked up where it is needed -- here for the input, again at the frame's end for the output -- rather than carried
+        // through the passes: five more values live across the pass loop cost the 12-wavefront shape its 80-register budget.
+        const int fu = __builtin_amdgcn_readfirstlane(f);
+        const uint8_t* frame;
+        const int32_t* b_sizes;
+        int fl;                                            // index inside its batch
+        {
+            const uint8_t* b_frames = job.batch[0].frames;
+            b_sizes = job.batch[0].max_sizes;
+            int b_first = 0;
+#pragma unroll
+            for (int i = 1; i < kMaxBatches; i++)
+                if (i < job.n_batches && fu >= job.batch[i].first) {
+                    b_frames = job.batch[i].frames; b_sizes = job.batch[i].max_sizes; b_first = job.batch[i].first;
+                }
+            fl = fu - b_first;
+            frame = b_frames + (size_t)fl * job.frame_stride;
+        }
+        int max_size = b_sizes ? b_sizes[fl] : job.uniform_max_size;
         // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
         // the output row)] is treated as "nothing fits" (result quant_scale 64, no bytes written)
         const bool bad_budget = max_size < 8 || max_size > job.max_frame_size || (size_t)max_size > job.out_stride;
@@ -1649,12 +1692,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // from the batch's answers otherwise.  Not "the last frame finished": the frames that finish last are the ones
             // that needed a second pass, i.e. the minority answer -- it would poison the start of every following launch
             // (measured: 48 % of the frames restarted at the quarter mark instead of 16 %).
-            if (scale < 64 && f == job.n_frames - 1) job.ticket[2] = (unsigned)scale | ((unsigned)max_size << 8);
+            if (scale < 64 && f == job.n_frames - 1) *job.hint = (unsigned)scale | ((unsigned)max_size << 8);
             L.scalars[S_HINT] = scale < 64 ? scale : 0;
             L.scalars[S_HINT_BUDGET] = max_size;
             L.scalars[S_PUSHED] = 0;
         }
-        uint8_t* outp = job.out + (size_t)f * job.out_stride;
+        uint8_t* outp;
+        psxhip_mdec_result_t* b_results;
+        {
+            const int fu2 = __builtin_amdgcn_readfirstlane(f);
+            uint8_t* b_out = job.batch[0].out;
+            b_results = job.batch[0].results;
+            int b_first = 0;
+#pragma unroll
+            for (int i = 1; i < kMaxBatches; i++)
+                if (i < job.n_batches && fu2 >= job.batch[i].first) { b_out = job.batch[i].out; b_results = job.batch[i].results; b_first = job.batch[i].first; }
+            outp = b_out + (size_t)(fu2 - b_first) * job.out_stride;
+            b_results += fu2 - b_first;
+        }
 
         if (scale >= 64 || bad_budget) {
             // nothing fits (the reference asserts, mdec.c:723): zero output, flag the result
@@ -1663,7 +1718,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (tid == 0) {
                 psxhip_mdec_result_t r;
                 r.quant_scale = in_loop(64); r.bytes_used = 0; r.blocks_used = 0; r.uncomp_hwords_used = 0;
-                job.results[f] = r;
+                *b_results = r;
             }
             group_sync(5);      // everyone has read the verdict: the scalars may go
             end_of_frame(tid);
@@ -1744,7 +1799,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.out[1] = (h1 >> 16) | (h1 << 16);
                     psxhip_mdec_result_t r;
                     r.quant_scale = scale; r.bytes_used = bytes_used; r.blocks_used = blocks_used; r.uncomp_hwords_used = hwords;
-                    job.results[f] = r;
+                    *b_results = r;
                 }
             }
             group_sync(5);
@@ -1939,7 +1994,16 @@ extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t
 extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     const int waves_ = a->large ? kWavesLarge : kWavesSmall;
     FrameJob job;
-    job.frames = a->d_frames;
+    memset(&job, 0, sizeof job);
+    job.n_batches = a->n_batches;
+    for (int i = 0, first = 0; i < a->n_batches && i < kMaxBatches; i++) {
+        job.batch[i].frames = a->batches[i].d_frames;
+        job.batch[i].out = a->batches[i].d_out;
+        job.batch[i].results = a->batches[i].d_results;
+        job.batch[i].max_sizes = a->batches[i].d_frame_max_sizes;
+        job.batch[i].first = first;
+        first += a->batches[i].n_frames;
+    }
     job.frame_stride = a->frame_stride;
     job.width = a->width;
     job.height = a->height;
@@ -1947,16 +2011,14 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.ny = a->height / 16;
     job.nmb = job.nx * job.ny;
     job.n_frames = a->n_frames;
-    job.max_sizes = a->d_max_sizes;
     job.uniform_max_size = a->uniform_max_size;
-    job.out = a->d_out;
     job.out_stride = a->out_stride;
-    job.results = a->d_results;
     job.out_words = a->out_words;
     job.out_tile = a->out_tile;
     job.max_frame_size = a->max_frame_size;
     job.stg_words = a->stg_words;
     job.ticket = a->d_ticket;
+    job.hint = a->d_hint;
     job.retry = a->d_retry;
     job.retry_cap = a->retry_cap;
     job.retry_patience = a->retry_patience;

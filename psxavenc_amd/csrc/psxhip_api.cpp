@@ -57,7 +57,7 @@ extern "C" void psxhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* psxhip_last_error(void) { return g_err; }
-extern "C" const char* psxhip_version(void) { return "psxav_hip 0.3 (gfx950, " PSXHIP_MDEC_KERNEL_REV ")"; }
+extern "C" const char* psxhip_version(void) { return "psxav_hip 0.4 (gfx950, " PSXHIP_MDEC_KERNEL_REV ")"; }
 
 extern "C" int psxhip_device_count(void) {
     int n = 0;
@@ -69,15 +69,21 @@ int psxhip_ensure_device(int device) { return ensure_device(device); }
 
 // ------------------------------------------------------------------------------------------ MDEC
 
+constexpr int kLanes = 2;
 struct psxhip_mdec_ctx {
     int device, codec, width, height, nmb;
     int max_frame_size, out_words, stg_words;
     int groups_max;            // persistent grid size: compute units x resident groups per CU
     int large;                 // 1: one 16-wavefront group per CU (two 12-wavefront groups do not fit the LDS)
     size_t lds_bytes;
-    unsigned int* d_ticket;         // [128] frame hand-out counters, hint, retry queue pop tickets / state (a cache line each) (the kernel re-arms them when it ends)
-    unsigned int* d_retry;          // retry queue slots (frames a group hands on instead of running another pass over them)
+    unsigned int* d_ticket;         // [kLanes][128] per launch lane: frame hand-out counters, retry queue pop tickets / state (a cache line each) (the kernel re-arms them when it ends); word [2] of lane 0 is the hint all lanes share
+    unsigned int* d_retry;          // [kLanes][retry_cap] retry queue slots (frames a group hands on instead of running another pass over them)
     int retry_cap;
+    // launch lanes (psxhip_mdec_set_lanes): launches that own different counters may overlap
+    int lanes, next_lane;
+    hipStream_t lane_stream[2];
+    hipEvent_t lane_in[2], lane_done[2];
+    bool lane_pending[2];           // lane_done[l] has been recorded and no caller stream has been ordered behind it yet
     int retry_patience;
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
@@ -94,8 +100,7 @@ struct psxhip_mdec_ctx {
     uint8_t* h_in[2];                 // pinned
     uint8_t* h_out[2];                // pinned: output rows, then the chunk's results
     hipEvent_t chunk_done[2];
-    hipStream_t stream2;             // chunks alternate between the two streams: the copies of one overlap the kernel of the other
-    hipEvent_t kernel_done[2];       // ... while the kernels stay ordered (launches on a context are stream-ordered)
+    hipStream_t stream2;             // chunks alternate between the two streams (and the two launch lanes): copies and kernels of neighbouring chunks overlap
     int cap_frames;                   // frames per chunk the buffers hold
     size_t cap_out_stride;
 };
@@ -226,19 +231,19 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
 
-    HIP_TRY(hipMalloc((void**)&c->d_ticket, 128 * sizeof(unsigned int)), PSXHIP_ENOMEM);
-    HIP_TRY(hipMemset(c->d_ticket, 0, 128 * sizeof(unsigned int)), PSXHIP_EDEVICE);
+    c->lanes = 1;
+    HIP_TRY(hipMalloc((void**)&c->d_ticket, kLanes * 128 * sizeof(unsigned int)), PSXHIP_ENOMEM);
+    HIP_TRY(hipMemset(c->d_ticket, 0, kLanes * 128 * sizeof(unsigned int)), PSXHIP_EDEVICE);
     if (!getenv("PSXHIP_MDEC_NO_RETRY_QUEUE")) {      // experiments: frames are never handed on
         c->retry_cap = 1 << 16;
         c->retry_patience = 256;
         if (const char* e = getenv("PSXHIP_MDEC_QUEUE_PATIENCE")) c->retry_patience = atoi(e);      // tests: 0 exercises the give-up path
-        HIP_TRY(hipMalloc((void**)&c->d_retry, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_ENOMEM);
-        HIP_TRY(hipMemset(c->d_retry, 0xFF, (size_t)c->retry_cap * sizeof(unsigned int)), PSXHIP_EDEVICE);
+        HIP_TRY(hipMalloc((void**)&c->d_retry, (size_t)kLanes * c->retry_cap * sizeof(unsigned int)), PSXHIP_ENOMEM);
+        HIP_TRY(hipMemset(c->d_retry, 0xFF, (size_t)kLanes * c->retry_cap * sizeof(unsigned int)), PSXHIP_EDEVICE);
     }
     // (the host path's two streams are created when it is first used: a context that only ever launches on its caller's streams
     //  would otherwise take two of the device's few hardware queues -- streams are dealt onto them round-robin -- and with three
     //  contexts alive two callers' streams shared one queue: their launches ran one after the other)
-    for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->kernel_done[b], hipEventDisableTiming), PSXHIP_EDEVICE);
     c->n_cu = prop.multiProcessorCount;
     // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
     // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
@@ -275,6 +280,11 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (int l = 0; l < kLanes; l++) {
+        if (c->lane_stream[l]) { (void)hipStreamSynchronize(c->lane_stream[l]); (void)hipStreamDestroy(c->lane_stream[l]); }
+        if (c->lane_in[l]) (void)hipEventDestroy(c->lane_in[l]);
+        if (c->lane_done[l]) (void)hipEventDestroy(c->lane_done[l]);
+    }
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_retry) (void)hipFree(c->d_retry);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -283,11 +293,175 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     psxhip_mdec_free_staging(c);
     for (int b = 0; b < 2; b++)
         if (c->chunk_done[b]) (void)hipEventDestroy(c->chunk_done[b]);
-    for (int b = 0; b < 2; b++)
-        if (c->kernel_done[b]) (void)hipEventDestroy(c->kernel_done[b]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     free(c);
+}
+
+// One launch over the frames of `nb` batches (1 .. PSXHIP_MDEC_MAX_BATCHES, all vetted by the caller) on `stream`, with the
+// hand-out counters and the retry queue of launch lane `lane`.  Launches of one lane must be ordered (same stream, or events).
+static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batch_t* batches, int nb, size_t frame_stride,
+                            int uniform_max_size, size_t out_stride, hipStream_t stream) {
+    int n_frames = 0;
+    for (int i = 0; i < nb; i++) n_frames += batches[i].n_frames;
+    // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
+    // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
+    // of all.  (Tried and dropped: sending the REMAINDER of a large batch -- the frames past the last full round of
+    // groups_max, when they are at most one per CU -- through that shape as a second launch.  1250 frames of 640x480 are
+    // 2.44 rounds and the mean group is resident 76 % of the launch, but the frame tickets already let early finishers
+    // start the third round while others are in their second; a second launch puts a barrier there instead: 1.176 ms
+    // against 1.144 ms.)
+    const bool small_batch = c->d_order_large && n_frames <= c->n_cu;
+    psxhip_mdec_launch_t a;
+    a.batches = batches;
+    a.n_batches = nb;
+    a.frame_stride = frame_stride;
+    a.width = c->width;
+    a.height = c->height;
+    a.codec = c->codec;
+    a.n_frames = n_frames;
+    a.uniform_max_size = uniform_max_size;
+    a.out_stride = out_stride;
+    a.out_words = c->out_words;
+    a.out_tile = c->out_words - 2;
+    a.max_frame_size = c->max_frame_size;
+    a.stg_words = c->stg_words;
+    a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
+    a.large = c->large || small_batch;
+    a.stream = stream;
+    a.d_ticket = c->d_ticket + 128 * lane;
+    a.d_hint = c->d_ticket + 2;
+    // frames are handed on only when a group can hold more than one (else nobody is left to take them), the queue has a slot per
+    // frame, and a group holds FEW: from about eight frames per group on the fresh-frame tickets level the groups by themselves,
+    // and a frame restarted on another XCD is read from HBM again (10 000 x 640x480: -1 % time, +8 % traffic with the queue)
+    const bool queue = c->d_retry && n_frames > a.grid && n_frames <= 8 * a.grid && n_frames < c->retry_cap;
+    a.d_retry = queue ? c->d_retry + (size_t)lane * c->retry_cap : nullptr;
+    a.retry_cap = queue ? c->retry_cap : 0;
+    a.retry_patience = c->retry_patience;
+    a.d_order = small_batch ? c->d_order_large : c->d_order;
+    a.d_stats = c->d_stats;
+    a.prio_pattern = c->prio_pattern;
+    a.ck_margin = c->ck_margin;
+    HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
+    return PSXHIP_OK;
+}
+
+static int mdec_ensure_lanes(psxhip_mdec_ctx* c) {
+    for (int l = 0; l < kLanes; l++) {
+        if (!c->lane_stream[l]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking), PSXHIP_EDEVICE);
+        if (!c->lane_in[l]) HIP_TRY(hipEventCreateWithFlags(&c->lane_in[l], hipEventDisableTiming), PSXHIP_EDEVICE);
+        if (!c->lane_done[l]) HIP_TRY(hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming), PSXHIP_EDEVICE);
+    }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_fence(psxhip_mdec_ctx_t* c, void* stream) {
+    if (!c) return PSXHIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    for (int l = 0; l < kLanes; l++)
+        if (c->lane_pending[l]) {
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->lane_done[l], 0), PSXHIP_EDEVICE);
+            c->lane_pending[l] = false;
+        }
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_set_lanes(psxhip_mdec_ctx_t* c, int lanes) {
+    if (!c || lanes < 1 || lanes > kLanes) {
+        psxhip_set_error("psxhip_mdec_set_lanes: 1 or %d lanes", kLanes);
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    for (int l = 0; l < kLanes; l++) {          // nothing of the old regime is left in flight
+        if (c->lane_stream[l]) HIP_TRY(hipStreamSynchronize(c->lane_stream[l]), PSXHIP_EDEVICE);
+        c->lane_pending[l] = false;
+    }
+    if (lanes > 1) { const int rc = mdec_ensure_lanes(c); if (rc) return rc; }
+    c->lanes = lanes;
+    c->next_lane = 0;
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_watchdog(psxhip_mdec_ctx_t* c, unsigned* lost) {
+    if (!c || !lost) return PSXHIP_EINVAL;
+    *lost = 0;
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    HIP_TRY(hipDeviceSynchronize(), PSXHIP_EDEVICE);
+    unsigned w[kLanes * 128];
+    HIP_TRY(hipMemcpy(w, c->d_ticket, sizeof w, hipMemcpyDeviceToHost), PSXHIP_EDEVICE);
+    for (int l = 0; l < kLanes; l++) *lost += w[128 * l + 3];
+    return PSXHIP_OK;
+}
+
+extern "C" int psxhip_mdec_encode_batches_device(psxhip_mdec_ctx_t* c, const psxhip_mdec_batch_t* batches, int n_batches,
+                                                 size_t frame_stride, int uniform_max_size, size_t out_stride, void* stream) {
+    if (!c || !batches || n_batches < 0) {
+        psxhip_set_error("encode_batches_device: NULL argument");
+        return PSXHIP_EINVAL;
+    }
+    const size_t fsz = (size_t)c->width * c->height * 3 / 2;
+    if (frame_stride < fsz || (frame_stride & 3) || (out_stride & 3)) {
+        psxhip_set_error("encode_frames_device: strides / pointers must be 4-byte aligned and frame_stride >= w*h*3/2");
+        return PSXHIP_EINVAL;
+    }
+    bool any_uniform = false;
+    long long total = 0;
+    for (int i = 0; i < n_batches; i++) {
+        const psxhip_mdec_batch_t& b = batches[i];
+        if (b.n_frames < 0 || (b.n_frames > 0 && (!b.d_frames || !b.d_out || !b.d_results))) {
+            psxhip_set_error("encode_frames_device: NULL argument (batch %d)", i);
+            return PSXHIP_EINVAL;
+        }
+        if (b.n_frames > 0 && (((uintptr_t)b.d_frames & 3) || ((uintptr_t)b.d_out & 3))) {
+            psxhip_set_error("encode_frames_device: strides / pointers must be 4-byte aligned and frame_stride >= w*h*3/2");
+            return PSXHIP_EINVAL;
+        }
+        if (b.n_frames > 0 && !b.d_frame_max_sizes) any_uniform = true;
+        total += b.n_frames;
+    }
+    if (any_uniform && (uniform_max_size < 8 || uniform_max_size > c->max_frame_size || (size_t)uniform_max_size > out_stride)) {
+        psxhip_set_error("encode_frames_device: frame_max_size %d outside [8, %d] or larger than out_stride",
+                         uniform_max_size, c->max_frame_size);
+        return PSXHIP_EINVAL;
+    }
+    if (total == 0) return PSXHIP_OK;
+    if (total > 0xFFFFFF) {          // (the retry queue's entries carry 24 bits of frame index)
+        psxhip_set_error("encode_frames_device: more than 16 777 215 frames in one call");
+        return PSXHIP_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    hipStream_t S = (hipStream_t)stream;
+    // groups of up to PSXHIP_MDEC_MAX_BATCHES non-empty batches, one launch each
+    psxhip_mdec_batch_t grp[PSXHIP_MDEC_MAX_BATCHES];
+    int ng = 0;
+    for (int i = 0; i <= n_batches; i++) {
+        if (i < n_batches && batches[i].n_frames > 0) grp[ng++] = batches[i];
+        if (ng == 0 || (ng < PSXHIP_MDEC_MAX_BATCHES && i < n_batches)) continue;
+        int rc;
+        if (c->lanes <= 1) {
+            rc = mdec_launch_lane(c, 0, grp, ng, frame_stride, uniform_max_size, out_stride, S);
+        } else {
+            // launch k on lane k % lanes, on the lane's own stream: it waits for the caller's stream as it stands now (inputs), and
+            // the caller's stream is ordered behind the launch BEFORE this one -- launch k itself stays outstanding, so that
+            // launch k + 1 (the other lane: other counters) can start while launch k's last frames finish
+            const int lane = c->next_lane, prev = (lane + kLanes - 1) % kLanes;
+            c->next_lane = (lane + 1) % c->lanes;
+            HIP_TRY(hipEventRecord(c->lane_in[lane], S), PSXHIP_EDEVICE);
+            HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_in[lane], 0), PSXHIP_EDEVICE);
+            rc = mdec_launch_lane(c, lane, grp, ng, frame_stride, uniform_max_size, out_stride, c->lane_stream[lane]);
+            if (rc == PSXHIP_OK) {
+                HIP_TRY(hipEventRecord(c->lane_done[lane], c->lane_stream[lane]), PSXHIP_EDEVICE);
+                c->lane_pending[lane] = true;
+                if (prev != lane && c->lane_pending[prev]) {
+                    HIP_TRY(hipStreamWaitEvent(S, c->lane_done[prev], 0), PSXHIP_EDEVICE);
+                    c->lane_pending[prev] = false;
+                }
+            }
+        }
+        if (rc) return rc;
+        ng = 0;
+    }
+    return PSXHIP_OK;
 }
 
 extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint8_t* d_frames, size_t frame_stride,
@@ -298,61 +472,14 @@ extern "C" int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t* c, const uint
         psxhip_set_error("encode_frames_device: NULL argument");
         return PSXHIP_EINVAL;
     }
-    if (n_frames == 0) return PSXHIP_OK;
-    const size_t fsz = (size_t)c->width * c->height * 3 / 2;
-    if (frame_stride < fsz || (frame_stride & 3) || (out_stride & 3) || ((uintptr_t)d_frames & 3) ||
-        ((uintptr_t)d_out & 3)) {
-        psxhip_set_error("encode_frames_device: strides / pointers must be 4-byte aligned and frame_stride >= w*h*3/2");
-        return PSXHIP_EINVAL;
-    }
-    if (!d_frame_max_sizes && (uniform_max_size < 8 || uniform_max_size > c->max_frame_size ||
-                               (size_t)uniform_max_size > out_stride)) {
-        psxhip_set_error("encode_frames_device: frame_max_size %d outside [8, %d] or larger than out_stride",
-                         uniform_max_size, c->max_frame_size);
-        return PSXHIP_EINVAL;
-    }
-    HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
-    // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
-    // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
-    // of all.  (Tried and dropped: sending the REMAINDER of a large batch -- the frames past the last full round of
-    // groups_max, when they are at most one per CU -- through that shape as a second launch.  1250 frames of 640x480 are
-    // 2.44 rounds and the mean group is resident 76 % of the launch, but the frame tickets already let early finishers
-    // start the third round while others are in their second; a second launch puts a barrier there instead: 1.176 ms
-    // against 1.144 ms.)
-    const bool small_batch = c->d_order_large && n_frames <= c->n_cu;
-    psxhip_mdec_launch_t a;
-    a.d_frames = d_frames;
-    a.frame_stride = frame_stride;
-    a.width = c->width;
-    a.height = c->height;
-    a.codec = c->codec;
-    a.n_frames = n_frames;
-    a.d_max_sizes = d_frame_max_sizes;
-    a.uniform_max_size = uniform_max_size;
-    a.d_out = d_out;
-    a.out_stride = out_stride;
-    a.d_results = d_results;
-    a.out_words = c->out_words;
-    a.out_tile = c->out_words - 2;
-    a.max_frame_size = c->max_frame_size;
-    a.stg_words = c->stg_words;
-    a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
-    a.large = c->large || small_batch;
-    a.stream = stream;
-    a.d_ticket = c->d_ticket;
-    // frames are handed on only when a group can hold more than one (else nobody is left to take them), the queue has a slot per
-    // frame, and a group holds FEW: from about eight frames per group on the fresh-frame tickets level the groups by themselves,
-    // and a frame restarted on another XCD is read from HBM again (10 000 x 640x480: -1 % time, +8 % traffic with the queue)
-    const bool queue = c->d_retry && n_frames > a.grid && n_frames <= 8 * a.grid && n_frames < c->retry_cap;
-    a.d_retry = queue ? c->d_retry : nullptr;
-    a.retry_cap = queue ? c->retry_cap : 0;
-    a.retry_patience = c->retry_patience;
-    a.d_order = small_batch ? c->d_order_large : c->d_order;
-    a.d_stats = c->d_stats;
-    a.prio_pattern = c->prio_pattern;
-    a.ck_margin = c->ck_margin;
-    HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
-    return PSXHIP_OK;
+    psxhip_mdec_batch_t b;
+    b.d_frames = d_frames;
+    b.n_frames = n_frames;
+    b.reserved = 0;
+    b.d_frame_max_sizes = d_frame_max_sizes;
+    b.d_out = d_out;
+    b.d_results = d_results;
+    return psxhip_mdec_encode_batches_device(c, &b, 1, frame_stride, uniform_max_size, out_stride, stream);
 }
 
 static void psxhip_mdec_free_staging(psxhip_mdec_ctx* c) {
@@ -515,13 +642,13 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             // rows are handed back max_size wide; bytes past a frame's own (smaller) budget read as zero
             HIP_TRY(hipMemsetAsync(c->d_out[b], 0, os * (size_t)cnt, st), PSXHIP_EDEVICE);
         }
-        // the kernels of consecutive chunks run in order (they share the context's frame tickets); everything else of a
-        // chunk overlaps its neighbours
-        if (k >= 1) HIP_TRY(hipStreamWaitEvent(st, c->kernel_done[b ^ 1], 0), PSXHIP_EDEVICE);
-        int rc = psxhip_mdec_encode_frames_device(c, c->d_frames[b], fsz, cnt, frame_max_sizes ? c->d_sizes[b] : nullptr,
-                                                  uniform_max_size, c->d_out[b], os, c->d_res[b], st);
+        // chunk k runs on launch lane k & 1 = its stream's own set of frame tickets: neighbouring chunks' kernels overlap like
+        // their copies do (the tail of one launch is filled by the head of the next); chunks k and k + 2 share stream and lane
+        psxhip_mdec_batch_t bd;
+        bd.d_frames = c->d_frames[b]; bd.n_frames = cnt; bd.reserved = 0; bd.d_frame_max_sizes = frame_max_sizes ? c->d_sizes[b] : nullptr;
+        bd.d_out = c->d_out[b]; bd.d_results = c->d_res[b];
+        int rc = mdec_launch_lane(c, b, &bd, 1, fsz, uniform_max_size, os, st);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(c->kernel_done[b], st), PSXHIP_EDEVICE);
         if (out_pinned) {
             HIP_TRY(hipMemcpy2DAsync(out + (size_t)first * out_stride, out_stride, c->d_out[b], os, (size_t)max_size, (size_t)cnt,
                                      hipMemcpyDeviceToHost, st), PSXHIP_EDEVICE);

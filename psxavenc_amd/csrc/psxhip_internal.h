@@ -7,22 +7,20 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.1"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.2"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 typedef struct {
-	const uint8_t *d_frames;
+	const psxhip_mdec_batch_t *batches;   /* [n_batches], 1 .. PSXHIP_MDEC_MAX_BATCHES (host memory; copied into the kernel arguments) */
+	int n_batches;
 	size_t frame_stride;
 	int width, height, codec;
-	int n_frames;
-	const int32_t *d_max_sizes;
+	int n_frames;                         /* over all batches */
 	int uniform_max_size;
-	uint8_t *d_out;
 	size_t out_stride;
-	psxhip_mdec_result_t *d_results;
 	int out_words;      /* LDS dwords of the frame image tile: out_tile + 2 */
 	int out_tile;       /* image dwords assembled in LDS at a time: min((max_frame_size + 3) / 4, 2048) */
 	int max_frame_size; /* the context's largest budget */
@@ -30,7 +28,8 @@ typedef struct {
 	int grid;
 	int large;          /* 1: 16-wavefront groups, one per CU (large frames / budgets) */
 	void *stream;
-	unsigned int *d_ticket;         /* [128] frame hand-out counters, hint, retry queue words: zero between launches */
+	unsigned int *d_ticket;         /* [128] of the launch's lane: frame hand-out counters, retry queue words: zero between launches */
+	unsigned int *d_hint;           /* one word shared by the context's lanes: the answer the next launch's groups start from */
 	unsigned int *d_retry;          /* [retry_cap] retry queue slots, all 0xFFFFFFFF between launches; NULL = frames are never handed on */
 	int retry_cap;
 	int retry_patience;             /* looks a group without work waits for a handed-on frame before it leaves */

@@ -122,10 +122,27 @@ extern "C" int psxhip_mdec_multi_encode_frames_host(psxhip_mdec_multi_t* m, cons
         ticket_frames = 1536;
         while (ticket_frames > 64 && (int64_t)ticket_frames * nd * 8 > n_frames) ticket_frames /= 2;
     }
+    // the whole batch is vetted before any shard runs, like the single-device call does (a bad budget must not leave the other
+    // shards' rows written, and the index reported is the call's, not a shard's)
+    const int cap = m->max_frame_size;
     int row_bytes = 0;                     // per-frame budgets: every row as wide as the unsplit call writes it
-    if (frame_max_sizes)
-        for (int i = 0; i < n_frames; i++)
+    if (frame_max_sizes) {
+        for (int i = 0; i < n_frames; i++) {
+            if (frame_max_sizes[i] < 8 || frame_max_sizes[i] > cap) {
+                psxhip_set_error("psxhip_mdec_multi_encode_frames_host: frame %d budget %d outside [8, %d]", i, frame_max_sizes[i], cap);
+                return PSXHIP_EINVAL;
+            }
             if (frame_max_sizes[i] > row_bytes) row_bytes = frame_max_sizes[i];
+        }
+    } else if (uniform_max_size < 8 || uniform_max_size > cap) {
+        psxhip_set_error("psxhip_mdec_multi_encode_frames_host: frame_max_size %d outside [8, %d]", uniform_max_size, cap);
+        return PSXHIP_EINVAL;
+    }
+    if ((size_t)(frame_max_sizes ? row_bytes : uniform_max_size) > out_stride) {
+        psxhip_set_error("psxhip_mdec_multi_encode_frames_host: out_stride %zu smaller than the largest budget %d", out_stride,
+                         frame_max_sizes ? row_bytes : uniform_max_size);
+        return PSXHIP_EINVAL;
+    }
     psxhip_ticket_queue_t* q = schedule == PSXHIP_SCHED_TICKETS ? psxhip_ticket_queue_create(n_frames, ticket_frames) : nullptr;
     if (schedule == PSXHIP_SCHED_TICKETS && !q) return PSXHIP_ENOMEM;
 
@@ -191,9 +208,21 @@ extern "C" int psxhip_xa_encode_streams_host_multi(const int* devices, int n_dev
                                                    int n_streams, int64_t stream_stride, int samples_per_stream,
                                                    const int32_t* lbas, psxhip_adpcm_state_t* states, uint8_t* out,
                                                    int64_t out_stride, int finalize, psxhip_multi_report_t* report) {
-    if (!devices || n_devices < 1 || n_devices > 64 || n_streams < 0) {
+    if (!devices || n_devices < 1 || n_devices > 64 || n_streams < 0 || !samples || !states || !out) {
         psxhip_set_error("psxhip_xa_encode_streams_host_multi: bad argument");
         return PSXHIP_EINVAL;
+    }
+    {   // (checked here, before any pointer is offset by a shard's first stream and before any thread is started)
+        const int have = psxhip_device_count();
+        if (have <= 0) {
+            psxhip_set_error("no HIP device visible (libpsxav_hip has no CPU fallback)");
+            return PSXHIP_EDEVICE;
+        }
+        for (int i = 0; i < n_devices; i++)
+            if (devices[i] < 0 || devices[i] >= have) {
+                psxhip_set_error("psxhip_xa_encode_streams_host_multi: device %d out of range (%d visible)", devices[i], have);
+                return PSXHIP_EINVAL;
+            }
     }
     const int nd = n_devices < n_streams ? n_devices : (n_streams > 0 ? n_streams : 1);
     if (report)

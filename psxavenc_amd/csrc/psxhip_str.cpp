@@ -150,6 +150,9 @@ int make_plan(const psxhip_str_settings_t* s, int n_frames, int64_t pcm_samples_
         else video = (n % interleave) > 0;
         Sector sec;
         if (video) {
+            // a video slot with no frame left to start (n_frames == 0: the reference asserts in its decoder's retire_av_data, there
+            // is nothing to mirror): the stream ends here -- empty, or the audio sectors before this slot
+            if (offset >= max_size && V <= 0) break;
             while (offset >= max_size) {                       // encode_sector_str moves on to the next frame, mdec.c:768-780
                 frame++;
                 num += pl->base;
@@ -289,6 +292,10 @@ extern "C" int psxhip_str_encode_host(psxhip_str_ctx_t* c, const psxhip_str_sett
     const int ns = pl.pub.n_sectors;
     if (ns == 0) return PSXHIP_OK;
     const int nf = pl.pub.n_frames_encoded;
+    if (nf > n_frames) {      // (a plan never takes a frame the caller did not hand over)
+        psxhip_set_error("psxhip_str_encode_host: internal error: plan encodes %d of %d frames", nf, n_frames);
+        return PSXHIP_EINVAL;
+    }
     if ((nf && !frames) || !out || (s->audio_channels && !pcm && pcm_samples_per_channel > 0)) {
         psxhip_set_error("psxhip_str_encode_host: NULL argument");
         return PSXHIP_EINVAL;

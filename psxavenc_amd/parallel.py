@@ -110,7 +110,7 @@ def run_time_sharded(session, rank, world, dist, initial_states, device=None):
         final, flag = msg
         payload = torch.tensor(np.concatenate([final.reshape(-1), [flag]]).astype(np.int64), device=device)
         outs = [torch.zeros_like(payload) for _ in range(world)]
-        if world > 1:
+        if dist is not None:      # (also at world size 1 when a group was forced: the collective then runs, over one rank)
             dist.all_gather(outs, payload)
         else:
             outs = [payload]

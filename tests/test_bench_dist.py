@@ -1,0 +1,92 @@
+"""bench.py's distributed leg and failure reporting.
+
+`-m gpu`: the RCCL leg at world size 1 -- `torch.distributed.run --nproc-per-node 1` exactly as the driver starts N ranks,
+`init_process_group("nccl", device_id=...)`, `barrier(device_ids=...)`, the float64 all_gather of device tensors -- for all
+four BASELINE presets, so that the first 8-GPU run is not the first time that code executes on hardware (the sharded loop is
+the reference's per-file loop, psxavenc/filefmt.c:633-662).
+`-m "not gpu"`: a failing rank prints ONE JSON line on stdout and exits non-zero."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _last_json(stdout):
+    for ln in reversed(stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return None
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return env
+
+
+PRESET_ARGS = {
+    "sbs_v2": ["--launches-per-step", "20"],
+    "sbs_v3": ["--total-frames", "1250", "--launches-per-step", "4"],
+    "xacd": ["--audio-seconds", "120"],
+    "strcd": ["--frames", "120"],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", sorted(PRESET_ARGS))
+def test_rccl_leg_at_world_size_1_under_torchrun(preset):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--config", preset,
+           "--steps", "2", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"] + PRESET_ARGS[preset]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode == 0 and line is not None, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "error" not in line, line
+    assert line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["forced_at_world_size_1"]
+    assert line["dist"]["exchange_tensors_on"] == "device"
+    assert line["parity"]["bit_exact"] is True
+    assert line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_forced_group_without_torchrun_sets_up_its_own_rendezvous():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1", "--launches-per-step", "8",
+                        "--no-secondary", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode == 0 and line and line["dist"]["backend"] == "nccl", (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bad_geometry_is_one_json_error_line_on_the_gpu_box():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--width", "328", "--steps", "1", "--warmup", "0", "--no-secondary",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode != 0 and line and "error" in line and line["rank"] == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_a_failing_rank_prints_one_json_error_line():
+    """(CPU container: no GPU -> the product path refuses; on a GPU box the world-size mismatch does the failing)"""
+    env = _env()
+    env.update(RANK="1", WORLD_SIZE="3", LOCAL_RANK="1")       # --gpus 2 against WORLD_SIZE 3
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode != 0
+    assert line is not None and "error" in line, (r.stdout[-1000:], r.stderr[-1000:])
+    assert line["rank"] == 1 and line["world_size"] == 3
+    assert len(r.stdout.strip().splitlines()) == 1

@@ -41,6 +41,25 @@ def test_str_plan_and_budgets_config_strcd():
         strmux.plan(strmux.settings(tail=7), 4)
 
 
+@pytest.mark.parametrize("tail", [0, 1])
+@pytest.mark.parametrize("channels,trailing", [(0, False), (2, False), (2, True), (1, True)])
+def test_str_plan_never_takes_a_frame_it_was_not_given(channels, trailing, tail):
+    """n_frames = 0 (the reference asserts in its decoder there -- nothing to mirror) must not plan frame 0; n_frames = 1 plans it"""
+    from psxavenc_amd import strmux
+    for pcm in (0, 1000, 5000, strmux.PLENTY_OF_AUDIO):
+        s = strmux.settings(channels=channels, trailing_audio=trailing, tail=tail, fmt=strmux.FORMAT_STRCD if channels else strmux.FORMAT_STRV)
+        p0 = strmux.plan(s, 0, pcm)
+        assert p0.n_frames_encoded == 0 and p0.n_video_sectors == 0
+        rows = strmux.plan_sectors(s, 0, pcm)
+        assert rows.shape[0] == p0.n_sectors and not (rows[:, 0] == strmux.SECTOR_VIDEO).any()
+        p1 = strmux.plan(s, 1, pcm)
+        assert p1.n_frames_encoded <= 1
+        rows = strmux.plan_sectors(s, 1, pcm)
+        assert (rows[rows[:, 0] == strmux.SECTOR_VIDEO][:, 1] == 0).all()
+        for n in (2, 3, 7):
+            assert strmux.plan(s, n, pcm).n_frames_encoded <= n
+
+
 def _stream_structure(stream, fmt):
     """(kind, frame, index, eof) per sector, read back from the bytes the reference's loop produced"""
     at = {6: 0x08, 7: 0x18, 9: 0x00}[fmt]
