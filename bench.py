@@ -349,6 +349,14 @@ def _main():
     ns = max(1, args.streams)
     encs = [MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank) for _ in range(ns)]
     enc = encs[0]
+    # launch lanes of the ONE context on the ONE caller stream (psxhip_mdec_set_lanes): 2 = consecutive launches may overlap (a
+    # launch's tail is filled by the next one's head); the caller double-buffers its outputs (one buffer per distinct batch here)
+    # and orders itself behind the last launch with psxhip_mdec_fence at the end of every step
+    lanes = args.lanes if args.lanes is not None else (2 if ns == 1 and nb >= 2 else 1)
+    if ns > 1:
+        lanes = 1
+    if lanes > 1:
+        enc.set_lanes(lanes)
     geo = query_geometry(args.codec, w, h, budget, device=local_rank)
     # `nb` distinct batches of this rank's frames: batch b = the same frame indices drawn with seed + b
     d_batches = [synth.frames_device(w, h, args.seed + b, first, n, args.amp, device=local_rank) for b in range(nb)]
@@ -370,6 +378,8 @@ def _main():
 
     for k in range(args.warmup * lps):
         launch(k)
+    if lanes > 1:
+        enc.fence(streams[0])
     torch.cuda.synchronize()
 
     # HIP events on the stream the kernel is launched on (torch's current stream).  One pair per STEP, bracketing its `lps`
@@ -392,6 +402,8 @@ def _main():
             if not per_step:
                 ev[k][1].record(streams[k % ns])
         if per_step:
+            if lanes > 1:
+                enc.fence(streams[0])          # the step's last launch is ordered into the stream: the event below sees all of them
             ev[s_][1].record(streams[0])
     _barrier(args, dist, local_rank)
     elapsed_local = time.perf_counter() - t0
@@ -402,6 +414,25 @@ def _main():
     achieved_local = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
     if ns > 1:      # launches overlap: a launch's own duration says little, the aggregate rate is what the GPU sustains
         achieved_local = alg_bytes * args.steps * lps / elapsed_local / 1e9
+    in_order = None
+    if lanes > 1:
+        # the same launches in strict stream order (one lane), right after the timed region: a launch's own duration, the figure
+        # rocprofv3's per-kernel average of an in-order run agrees with
+        enc.set_lanes(1)
+        m = min(lps, 400)
+        for k in range(m // 4):
+            launch(k)
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record(streams[0])
+        for k in range(m):
+            launch(k)
+        b_.record(streams[0])
+        torch.cuda.synchronize()
+        io_ms = a_.elapsed_time(b_) / m
+        in_order = {"lanes": 1, "kernel_ms": round(io_ms, 5), "launches": m, "frames_per_sec": round(n / io_ms * 1e3, 1),
+                    "achieved": round((fsz + budget) * n / (io_ms * 1e-3) / 1e9, 3), "frac": round((fsz + budget) * n / (io_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "note": "one launch at a time (psxhip_mdec_set_lanes(1)): every launch waits for the one before, HIP events around %d back-to-back launches" % m}
+        enc.set_lanes(lanes)
     per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps), kstat["mean"], achieved_local])
     elapsed = max(r[0] for r in per_rank)                   # max over ranks
 
@@ -446,7 +477,7 @@ def _main():
     issue = None
     if pmc and pmc.get("valu_insts_per_launch") and not getattr(args, "share_gpu", False):      # (ranks sharing one GPU: a rank's kernel time is not the GPU's)
         simds, clock_ghz = 256 * 4, 2.4
-        eff_ms = kstat["mean"] if ns == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock
+        eff_ms = kstat["mean"] if ns == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock (with lanes the per-step event time / launches IS that share)
         slots = simds * clock_ghz * 1e9 / 4.0 * (eff_ms * 1e-3)
         issue = {"valu_insts_per_launch": pmc["valu_insts_per_launch"], "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
                  "lds_insts_per_launch": pmc.get("lds_insts_per_launch"),
@@ -486,7 +517,10 @@ def _main():
                        "kernel_shape": {"groups_per_cu": geo.groups_per_cu, "wavefronts_per_group": geo.wavefronts_per_group,
                                         "image_tile_bytes": geo.image_tile_bytes, "frames_in_flight": geo.frames_in_flight},
                        "quant_scale_hist": {str(int(s)): int(c) for s, c in zip(scales, counts)},
-                       "library": version, "streams": ns},
+                       "library": version, "streams": ns, "contexts": ns, "launch_lanes": lanes,
+                       "launch_order": ("one context, one caller stream, two launch lanes (psxhip_mdec_set_lanes): inputs stream-ordered, a launch's results ordered into the "
+                                        "stream by the next call / psxhip_mdec_fence at the end of each step; consecutive launches overlap") if lanes > 1 else
+                                       ("strict stream order: every launch waits for the one before" if ns == 1 else "%d contexts on %d streams" % (ns, ns))},
             "per_rank": [{"rank": i, "frames_per_sec": round(r[1] / r[0], 1), "elapsed_s": round(r[0], 4), "kernel_ms": round(r[2], 5),
                           "roofline_achieved_gbs": round(r[3], 2), "roofline_frac": round(r[3] / HBM_PEAK_GBS, 6),
                           "quant_scale_sum": int(q[0]), "results_sane": bool(q[1])} for i, (r, q) in enumerate(zip(per_rank, scale_sum))],
@@ -495,7 +529,10 @@ def _main():
                          "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
                          "launches_timed": args.steps * lps,
                          "kernel_ms_method": ("one HIP event pair per step of %d back-to-back launches, / %d; stats over steps" % (lps, lps)) if per_step else "one HIP event pair per launch",
-                         "algorithmic_bytes_per_launch": alg_bytes, "issue": issue,
+                         "algorithmic_bytes_per_launch": alg_bytes, "issue": issue, "in_order": in_order,
+                         **({"overlap_note": "with two launch lanes consecutive launches overlap: kernel_ms = a step's HIP-event time / its launches = a launch's SHARE "
+                                             "of the GPU's time (what the rate follows from); one launch by itself lasts in_order.kernel_ms, and in a kernel trace "
+                                             "of this run each kernel's own span is longer than its share because it runs beside its neighbour"} if lanes > 1 else {}),
                          **({"note": "launches of %d contexts overlap: achieved = algorithmic bytes of all launches / elapsed; kernel_ms are "
                                      "per-launch durations while sharing the GPU" % ns} if ns > 1 else {})},
             "cpu_baseline": cpu_baseline,
@@ -558,6 +595,33 @@ def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
             e.close()
     except Exception as e:
         out["two_contexts_two_streams"] = {"error": repr(e)}
+    # psxhip_mdec_encode_batches_device: a caller that holds four batches hands them over together -- one launch, frames of all four
+    # drawn from one ticket counter, no launch boundary between them, no concatenation of its buffers
+    try:
+        enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+        o4 = [(torch.zeros_like(d_out), torch.zeros_like(d_res)) for _ in range(4)]
+        res4 = {}
+        for amp_ in sorted({args.amp, 8}):
+            bb = [synth.frames_device(w, h, args.seed + 400 + b, first, n, amp_, device=local_rank) for b in range(4)]
+            lst = [(bb[i], o4[i][0], o4[i][1]) for i in range(4)]
+
+            def run(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    enc.encode_batches_device(lst, budget)
+                b.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+            run(4)
+            ms4 = run(50)
+            res4["noise_amp_%d" % amp_] = {"frames_per_sec": round(4 * n / ms4 * 1e3, 1), "ms_per_launch": round(ms4, 5), "launches": 50}
+        res4["batches_per_launch"] = 4
+        res4["frames_per_batch"] = n
+        out["four_batches_one_launch"] = res4
+        enc.close()
+    except Exception as e:
+        out["four_batches_one_launch"] = {"error": repr(e)}
     try:
         enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
         b8 = [synth.frames_device(w, h, args.seed + 100 + b, first, n, 8, device=local_rank) for b in range(4)]

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsxav_hip.so")
+# (PSXAV_HIP_LIB: another build of the same library, for A/B measurements of kernel revisions on one box)
+LIB_PATH = os.environ.get("PSXAV_HIP_LIB") or os.path.join(_HERE, "libpsxav_hip.so")
 
 PSXHIP_OK, PSXHIP_EINVAL, PSXHIP_EDEVICE, PSXHIP_ENOMEM, PSXHIP_ENOFIT = 0, -1, -2, -3, -4
 

@@ -16,7 +16,9 @@
 //   * the winning lane stores the unit's record and its decoded state is broadcast to the row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "psxhip_internal.h"
@@ -321,6 +323,193 @@ __global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The reference's own call pattern -- psx_audio_spu_encode once per 28 samples (filefmt.c:243), psx_audio_xa_encode once per
+// sector (filefmt.c:184) -- as ONE launch with nothing to copy around it: chain descriptors and start states ride in the
+// kernel arguments, the samples are read from page-locked host memory the device can see (staged into LDS first: one PCIe
+// round trip, then the serial chain runs out of LDS), SPU blocks leave packed (adpcm.c:367-372) straight into page-locked host
+// memory, final states likewise.  One wavefront, up to four chains.  (The batched path's four H2D copies, two kernels, two D2H
+// copies and a synchronise cost 94 us per 28-sample call against ~3 us for the reference's own loop.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kCallStageMax = 8192;      // int16 elements staged in LDS (an XA sector is 4032)
+constexpr int kCallWarm = 8;             // units a speculating row runs from a zero state before its segment
+constexpr int kCallSpecMin = 24;         // chains shorter than this are encoded serially (nothing to win)
+constexpr int kCallHist = 96;            // longest speculated segment
+struct CallJob {
+    const int16_t* samples;                 // device-visible; chains' sample_offset counts from here
+    psxhip_adpcm_chain_t chains[4];
+    psxhip_adpcm_state_t states_in[4];
+    int32_t unit_base[4];
+    int n_chains, filter_count, range;
+    int stage_elems;                        // > 0: copy this many elements into LDS first (multiple of 8, <= kCallStageMax)
+    psxhip_adpcm_state_t* states_out;
+    uint8_t* units;                         // 32-byte records (XA), or NULL
+    uint8_t* spu_out;                       // packed 16-byte SPU blocks, or NULL
+};
+
+__device__ __forceinline__ void store_spu_block(uint8_t* out, long long index, uint32_t header, const uint32_t* pk_lds, int lane) {
+    // [header][flags = 0][14 x (even | odd << 4)]  (adpcm.c:367-372); a word of pk_lds holds four codes, one per byte
+    uint32_t nib[7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        const uint32_t c = pk_lds[w * 64 + lane];
+        nib[w] = (c & 0x0Fu) | (((c >> 8) & 0x0Fu) << 4) | (((c >> 16) & 0x0Fu) << 8) | (((c >> 24) & 0x0Fu) << 12);     // two packed bytes
+    }
+    uint4 v;
+    v.x = (header & 0xFFu) | (nib[0] << 16);
+    v.y = nib[1] | (nib[2] << 16);
+    v.z = nib[3] | (nib[4] << 16);
+    v.w = nib[5] | (nib[6] << 16);
+    *(uint4*)(out + index * 16) = v;
+}
+
+__global__ __launch_bounds__(64) void adpcm_call_kernel(const CallJob job) {
+    const int lane = (int)(threadIdx.x & 63);
+    const Candidate cd = make_candidate<16>(lane, job.filter_count, job.range);
+    __shared__ __attribute__((aligned(16))) int16_t stage[kCallStageMax];
+    __shared__ int xs_all[4][32];
+    __shared__ uint32_t pk_lds[7 * 64];
+
+    const int16_t* base = job.samples;
+    if (job.stage_elems > 0) {
+        // all loads of a round in flight before the first is waited for (the source is on the far side of the PCIe link)
+        const uint4* src16 = (const uint4*)job.samples;
+        uint4* dst16 = (uint4*)stage;
+        const int n16 = job.stage_elems >> 3;
+        for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * 64 + lane;
+                v[k] = i < n16 ? src16[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * 64 + lane;
+                if (i < n16) dst16[i] = v[k];
+            }
+        }
+        __syncthreads();
+        base = stage;
+    }
+    // ---- rows.  A wavefront has four rows; a call has 1-4 chains.  With one or two chains of some length the spare rows
+    //      SPECULATE (the scheme of adpcm_chunks_kernel inside one wavefront): a chain is cut into 4 / n_chains segments; segment 0
+    //      starts from the chain's true state, every other segment from a state guessed by running kCallWarm units before it
+    //      from zero, and keeps the state after each of its units.  Then the row that holds the truth (the "runner": segment 0's)
+    //      walks the boundaries: a segment whose guess was the truth stands; otherwise the runner re-encodes it from the truth
+    //      until its state coincides with the kept one -- from there on the segment stands as well (the unit encoder is a
+    //      function of state and samples).  Worst case (states never coincide: pure tones) the runner re-encodes everything, i.e.
+    //      the serial schedule; typical material falls in within a few units, and a sector's 72 units per channel take 40 + a
+    //      few dependent unit encodes instead of 72.  The result is the serial encode's, bit for bit, whatever the guesses.
+    const int nc = job.n_chains;
+    const int nu = job.chains[0].n_units;
+    int nseg = nc == 1 ? 4 : (nc == 2 ? 2 : 1);
+    for (int c = 1; c < nc; c++)
+        if (job.chains[c].n_units != nu) nseg = 1;
+    if (nu < kCallSpecMin) nseg = 1;
+    int L0 = nu, Lr = 0;
+    if (nseg > 1) {
+        L0 = (nu + (nseg - 1) * kCallWarm + nseg - 1) / nseg;
+        Lr = (nu - L0 + nseg - 2) / (nseg - 1);
+        if (Lr > kCallHist || Lr < 1) { nseg = 1; L0 = nu; Lr = 0; }
+    }
+    const int row = lane >> 4, col = lane & 15;
+    const int seg = row / nc, c_of_row = row - seg * nc;           // (nc >= 1)
+    const bool row_live = row < nseg * nc;
+    const int seg_s = seg == 0 ? 0 : min(nu, L0 + (seg - 1) * Lr), seg_e = seg == 0 ? L0 : min(nu, seg_s + Lr);
+    __shared__ int2 hist[4][kCallHist];       // state after each unit of a speculated segment
+    __shared__ int2 guess[4];                 // state a speculated segment started from
+
+    psxhip_adpcm_chain_t ch;
+    ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
+    int prev1 = 0, prev2 = 0;
+    long long rec0 = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (c_of_row == c && row_live) {
+            ch = job.chains[c];
+            rec0 = job.unit_base[c];
+            if (seg == 0) {
+                prev1 = job.states_in[c].prev1;
+                prev2 = job.states_in[c].prev2;
+            }
+        }
+    const int16_t* src = base + ch.sample_offset;
+    int* xs = xs_all[row];
+    auto put = [&](int u, uint32_t header) {
+        if (job.spu_out) store_spu_block(job.spu_out, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
+        else store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
+    };
+    // ---- phase 1: every row its segment (the speculating rows start kCallWarm units early, from a zero state)
+    const int u0 = seg == 0 ? 0 : seg_s - kCallWarm;               // (L0 >= kCallWarm: never negative)
+    int t_max = row_live ? seg_e - u0 : 0;
+    t_max = max(t_max, __shfl_xor(t_max, 16, 64));
+    t_max = max(t_max, __shfl_xor(t_max, 32, 64));
+    UnitFetch nxt = fetch_unit<16>(src, ch, u0, row_live && u0 < seg_e, lane);
+    for (int t = 0; t < t_max; t++) {
+        const int u = u0 + t;
+        const bool unit_live = row_live && u < seg_e;
+        stage_unit<16>(xs, nxt, lane);
+        if (t + 1 < t_max) nxt = fetch_unit<16>(src, ch, u + 1, row_live && u + 1 < seg_e, lane);
+        if (unit_live && col == 0 && seg > 0 && u == seg_s) guess[row] = make_int2(prev1, prev2);
+        uint32_t header;
+        const bool won = encode_unit<16>(cd, xs, unit_live, lane, prev1, prev2, header, pk_lds);
+        if (won && unit_live && u >= seg_s) put(u, header);
+        if (unit_live && col == 0 && seg > 0 && u >= seg_s) hist[row][u - seg_s] = make_int2(prev1, prev2);
+    }
+    wave_sync();
+    // ---- phase 2: the runners (segment 0's rows) walk their chains' boundaries
+    if (nseg > 1) {
+        const bool runner = row < nc;
+        int b = 1, u = 0;
+        bool reenc = false;
+        for (;;) {
+            if (runner) {
+                while (!reenc && b < nseg) {
+                    const int rb = b * nc + row;
+                    const int sb = min(nu, L0 + (b - 1) * Lr), eb = min(nu, sb + Lr);
+                    if (sb >= eb) { b = nseg; break; }
+                    const int2 g = guess[rb];
+                    if (g.x == prev1 && g.y == prev2) {            // the guess was the truth: the segment stands
+                        const int2 h = hist[rb][eb - sb - 1];
+                        prev1 = h.x; prev2 = h.y;
+                        b++;
+                    } else {
+                        reenc = true;
+                        u = sb;
+                    }
+                }
+            }
+            const bool work = runner && reenc;
+            if (__ballot(work) == 0) break;
+            const UnitFetch f = fetch_unit<16>(src, ch, u, work, lane);
+            stage_unit<16>(xs, f, lane);
+            uint32_t header;
+            const bool won = encode_unit<16>(cd, xs, work, lane, prev1, prev2, header, pk_lds);
+            if (won && work) put(u, header);
+            if (work) {
+                const int rb = b * nc + row;
+                const int sb = min(nu, L0 + (b - 1) * Lr), eb = min(nu, sb + Lr);
+                const int2 h = hist[rb][u - sb];
+                u++;
+                if (h.x == prev1 && h.y == prev2) {                // fell into the speculated trajectory: the rest of the segment stands
+                    const int2 hl = hist[rb][eb - sb - 1];
+                    prev1 = hl.x; prev2 = hl.y;
+                    reenc = false;
+                    b++;
+                } else if (u == eb) {                              // re-encoded to its end: this IS the truth at the next boundary
+                    reenc = false;
+                    b++;
+                }
+            }
+        }
+    }
+    if (row < nc && col == 0) {
+        job.states_out[row].prev1 = prev1;
+        job.states_out[row].prev2 = prev2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Speculate-and-verify along time.  A chain is serial, but its whole carried state is the
 // pair (prev1, prev2), and encoders started from different states on the same samples usually fall into
 // the same state within a few units.  So a long chain is cut into chunks of `chunk_units`:
@@ -502,6 +691,7 @@ struct XaJob {
     const uint8_t* units;
     int n_sectors, format, stereo, frequency, bits, file_number, channel_number, first_lba;
     const uint8_t* eof_flags;   // optional: eof_flags[s] != 0 sets the EOF submode bit (adpcm.c:334-340)
+    uint32_t eof_bits;          // ... or, without eof_flags, bit s for the first 32 sectors (the per-sector call: nothing to upload)
     uint8_t* out;
 };
 
@@ -599,7 +789,7 @@ __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
         if (tid < 4) sec[0x92C + tid] = (uint8_t)(crc_part[0] >> (8 * tid));
         // psx_audio_xa_encode_finalize (adpcm.c:334-340) ORs EOF into both subheader copies AFTER the EDC was
         // computed and does not refresh it; kept that way for byte parity.
-        if (tid == 4 && job.eof_flags && job.eof_flags[s]) {
+        if (tid == 4 && (job.eof_flags ? job.eof_flags[s] != 0 : (s < 32 && ((job.eof_bits >> s) & 1u)))) {
             sec[18] |= 0x80;
             sec[22] = sec[18];
         }
@@ -642,6 +832,27 @@ extern "C" int psxhip_adpcm_encode_chains_device(int device, const int16_t* d_sa
     }
     return PSXHIP_OK;
 }
+
+extern "C" hipError_t psxhip_adpcm_call_launch(const psxhip_adpcm_call_t* a, void* stream) {
+    CallJob job;
+    memset(&job, 0, sizeof job);
+    job.samples = a->samples;
+    for (int c = 0; c < 4; c++) {
+        job.chains[c] = a->chains[c];
+        job.states_in[c] = a->states_in[c];
+        job.unit_base[c] = a->unit_base[c];
+    }
+    job.n_chains = a->n_chains;
+    job.filter_count = a->filter_count;
+    job.range = a->bits == 4 ? 12 : 8;
+    job.stage_elems = a->stage_elems;
+    job.states_out = a->states_out;
+    job.units = a->units;
+    job.spu_out = a->spu_out;
+    hipLaunchKernelGGL(adpcm_call_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, job);
+    return hipGetLastError();
+}
+extern "C" int psxhip_adpcm_call_stage_max(void) { return kCallStageMax; }
 
 // final state of every chain = state after its last unit
 __global__ void adpcm_gather_final_states_kernel(const psxhip_adpcm_chain_t* chains, const int64_t* state_base, int n_chains,
@@ -956,6 +1167,8 @@ extern "C" int psxhip_spu_pack_device(int device, const uint8_t* d_units, int n_
 // builds c_xa_tables on the host and uploads it, once per device
 static int xa_tables(int device) {
     static bool done[64] = {false};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (device >= 0 && device < 64 && done[device]) return PSXHIP_OK;
     uint32_t t[256 + 8 * 32];
     for (uint32_t i = 0; i < 256; i++) {
@@ -988,6 +1201,13 @@ static int xa_tables(int device) {
 extern "C" int psxhip_xa_assemble_device(int device, const uint8_t* d_units, int n_sectors, int format, int stereo,
                                          int frequency, int bits, int file_number, int channel_number, int first_lba,
                                          const uint8_t* d_eof_flags, uint8_t* d_out, void* stream) {
+    return psxhip_xa_assemble_device_bits(device, d_units, n_sectors, format, stereo, frequency, bits, file_number, channel_number, first_lba,
+                                          d_eof_flags, 0u, d_out, stream);
+}
+
+extern "C" int psxhip_xa_assemble_device_bits(int device, const uint8_t* d_units, int n_sectors, int format, int stereo,
+                                              int frequency, int bits, int file_number, int channel_number, int first_lba,
+                                              const uint8_t* d_eof_flags, uint32_t eof_bits, uint8_t* d_out, void* stream) {
     if (!d_units || !d_out || n_sectors < 0 || (format != 0 && format != 1) || (bits != 4 && bits != 8) ||
         ((uintptr_t)d_out & 3)) {
         psxhip_set_error("xa_assemble: bad argument");
@@ -1009,6 +1229,7 @@ extern "C" int psxhip_xa_assemble_device(int device, const uint8_t* d_units, int
     job.channel_number = channel_number;
     job.first_lba = first_lba;
     job.eof_flags = d_eof_flags;
+    job.eof_bits = eof_bits;
     job.out = d_out;
     hipLaunchKernelGGL(xa_assemble_kernel, dim3((unsigned)n_sectors), dim3(256), 0, (hipStream_t)stream, job);
     if (hipGetLastError() != hipSuccess) {

@@ -81,11 +81,10 @@ struct BatchDesc {
     uint8_t* out;
     psxhip_mdec_result_t* results;
     const int32_t* max_sizes;      // per-frame budgets of this batch, or NULL (the launch's uniform budget)
-    int first;                     // index of the batch's first frame in the launch
-    int reserved;
 };
 struct FrameJob {
-    BatchDesc batch[kMaxBatches];
+    BatchDesc batch[kMaxBatches];   // (first member: batch_table())
+    int first[kMaxBatches];         // index of each batch's first frame in the launch; INT_MAX for the entries past the last batch
     int n_batches;
     size_t frame_stride;
     int width, height, nx, ny, nmb;
@@ -108,6 +107,14 @@ struct FrameJob {
     int ck_margin;               // quarter-pass checkpoint: how far (thousandths of its standard error) a projection has to be on the wrong side
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
 };
+// the batch table where it lies in the kernel argument segment (FrameJob is the kernel's only argument, `batch` its first member)
+typedef const BatchDesc __attribute__((address_space(4))) * BatchPtr;
+typedef const int __attribute__((address_space(4))) * FirstPtr;
+__device__ __forceinline__ BatchPtr batch_table() {
+    BatchPtr p = (BatchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 __device__ __forceinline__ unsigned long long* queue_state(const FrameJob& job) { return (unsigned long long*)&job.ticket[kQueueWord]; }
 // the next fresh-frame ticket: the low half of the state word (what the waiting groups look at)
 __device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) { return (unsigned)atomicAdd(queue_state(job), 1ull); }
@@ -365,6 +372,7 @@ struct Lds {
 };
 
 static_assert(sizeof(MdecSearch) == 56 && (S_SEARCH % 2) == 0, "MdecSearch lives in scalars[S_SEARCH..+14)");
+static_assert(offsetof(FrameJob, batch) == 0 && offsetof(FrameJob, first) == sizeof(BatchDesc) * kMaxBatches, "batch_table() reads the table at the start of the kernel argument segment");
 constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + coefficient tile
 static_assert(kWaveTileBytes >= 384 * 4, "the per-wave code list (384 entries) aliases the tiles");
 
@@ -834,24 +842,26 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         lc.below = (1ull << lane) - 1ull;
         lc.lane_m64 = lane - 64;
         lc.zsrc = (int)L.tab_nat[lane];
-        // which batch the frame belongs to (wave-uniform: f comes from one LDS word; scalar selects over the kernel arguments).
-        // Looked up where it is needed -- here for the input, again at the frame's end for the output -- rather than carried
-        // through the passes: five more values live across the pass loop cost the 12-wavefront shape its 80-register budget.
+        // Which batch the frame belongs to (wave-uniform: f comes from one LDS word).  The batch table is read from the kernel
+        // argument segment WHERE it is needed, through a pointer the compiler cannot see through -- here for the input, again at
+        // the frame's end for the output: as plain members of `job` all 8 x 5 words were loaded at kernel entry and kept (spilled
+        // into vector registers: two more than the 12-wavefront shape's 80 has room for).
         const int fu = __builtin_amdgcn_readfirstlane(f);
         const uint8_t* frame;
         const int32_t* b_sizes;
         int fl;                                            // index inside its batch
-        {
-            const uint8_t* b_frames = job.batch[0].frames;
-            b_sizes = job.batch[0].max_sizes;
-            int b_first = 0;
+        int bi = 0;
+        fl = f;
+        b_sizes = job.batch[0].max_sizes;                  // one batch (the common launch): plain kernel arguments, nothing to look up
+        frame = job.batch[0].frames + (size_t)f * job.frame_stride;
+        if (job.n_batches > 1) {                           // (straight-line scalar code: a loop here cost the 12-wavefront shape two vector registers it does not have)
+            BatchPtr bt = batch_table();
+            FirstPtr ft = (FirstPtr)(bt + kMaxBatches);
 #pragma unroll
-            for (int i = 1; i < kMaxBatches; i++)
-                if (i < job.n_batches && fu >= job.batch[i].first) {
-                    b_frames = job.batch[i].frames; b_sizes = job.batch[i].max_sizes; b_first = job.batch[i].first;
-                }
-            fl = fu - b_first;
-            frame = b_frames + (size_t)fl * job.frame_stride;
+            for (int i = 1; i < kMaxBatches; i++) bi += fu >= ft[i] ? 1 : 0;
+            fl = fu - ft[bi];
+            b_sizes = bt[bi].max_sizes;
+            frame = bt[bi].frames + (size_t)fl * job.frame_stride;
         }
         int max_size = b_sizes ? b_sizes[fl] : job.uniform_max_size;
         // per-frame budgets live in device memory the host cannot vet: a budget outside [8, min(the context's maximum,
@@ -1058,12 +1068,28 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             plo = *(const uint2*)(frame + o_lo);
             phi = *(const uint2*)(frame + o_hi);
         };
-        // DCT of the macroblock whose pixels are in (plo, phi); prefetches the wavefront's next macroblock meanwhile
-        auto dct_mb = [&](bool have_next, int next_fx, int next_fy) {
-            const uint4 ts = L.tab_sel[lane];
-            const uint32_t b_lo = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
-            const uint32_t b_hi = __builtin_amdgcn_perm(phi.y, phi.x, ts.y);
-            if (have_next) fetch(next_fx, next_fy);          // (issued behind the matrix instruction instead, the loads leave 2 % later)
+        // the lane's 8 pixels as bytes (b_lo: p0..p3, b_hi: p4..p7) from what fetch() left in (plo, phi)
+        auto mb_bytes = [&](const uint4& ts, uint32_t& b_lo, uint32_t& b_hi) {
+            b_lo = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
+            b_hi = __builtin_amdgcn_perm(phi.y, phi.x, ts.y);
+        };
+        // ... and the fetch of the wavefront's NEXT macroblock behind them: always issued (a wavefront without a next macroblock
+        // re-reads the frame's first one), and tied to the bytes above by an empty asm, so that the loads land in the very
+        // registers the permutes have just read.  (Issued under `if (there is a next one)`, and hoisted above the permutes by
+        // the scheduler, the loads needed a second set of four registers and 8 v_mov per macroblock to shuttle between the sets
+        // -- 3 % of the loop's VALU instructions.)
+        auto fetch_behind = [&](int fx, int fy, uint32_t& b_lo, uint32_t& b_hi) {
+            asm volatile("" : "+v"(b_lo), "+v"(b_hi));
+            const uint4 tp = L.tab_pix[lane];
+            const uint32_t row = (uint32_t)fy * (uint32_t)(8 * W), col = (uint32_t)fx * 16u;
+            uint32_t o_lo = tp.x + (row << tp.z) + col;
+            asm volatile("" : "+v"(o_lo) : "v"(b_lo), "v"(b_hi));      // the address is "made from" the bytes: the loads stay behind the permutes
+            const uint32_t o_hi = o_lo + tp.y;
+            plo = *(const uint2*)(frame + o_lo);
+            phi = *(const uint2*)(frame + o_hi);
+        };
+        // DCT of the macroblock whose pixel bytes are (b_lo, b_hi)
+        auto dct_mb = [&](const uint4& ts, uint32_t b_lo, uint32_t b_hi) {
             int d[8];
             {
                 // -- row pass on the matrix pipe: every lane hands in its own row vector (lane = (block, row); lanes 48..63 idle
@@ -1125,7 +1151,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (pi < n_pilot) {
                 const MbCursor pc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
                 fetch(pc.fx, pc.fy);
-                dct_mb(false, 0, 0);
+                {
+                    const uint4 ts = L.tab_sel[lane];
+                    uint32_t b_lo, b_hi;
+                    mb_bytes(ts, b_lo, b_hi);
+                    dct_mb(ts, b_lo, b_hi);
+                }
 #pragma unroll
                 for (int b = 0; b < 6; b++) cf[b] = lane == 0 ? 0.0f : (float)(int)tileZ[b * kZStride + lc.zsrc];
                 wave_sync();
@@ -1342,10 +1373,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 int drawn = 0;
                 if (lane == 0) drawn = atomicAdd(&L.scalars[S_MB_NEXT], 1);
                 const bool valid = cur_o != kNoMb, nxt_valid = nxt_o != kNoMb;
-                const int nfx = (int)(nxt_o & 0xFFu), nfy = (int)(nxt_o >> 8);
+                const int nfx = nxt_valid ? (int)(nxt_o & 0xFFu) : 0, nfy = nxt_valid ? (int)(nxt_o >> 8) : 0;
                 const int mbe = (int)(cur_o & 0xFFu) * ny + (int)(cur_o >> 8);
-                if (valid) dct_mb(nxt_valid, nfx, nfy);
-                else if (nxt_valid) fetch(nfx, nfy);
+                {
+                    const uint4 ts = L.tab_sel[lane];
+                    uint32_t b_lo, b_hi;
+                    mb_bytes(ts, b_lo, b_hi);
+                    fetch_behind(nfx, nfy, b_lo, b_hi);
+                    if (valid) dct_mb(ts, b_lo, b_hi);
+                }
                 cur_t = nxt_t;
                 cur_o = nxt_o;
                 nxt_t = __builtin_amdgcn_readfirstlane(drawn);
@@ -1700,15 +1736,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         uint8_t* outp;
         psxhip_mdec_result_t* b_results;
         {
-            const int fu2 = __builtin_amdgcn_readfirstlane(f);
-            uint8_t* b_out = job.batch[0].out;
-            b_results = job.batch[0].results;
-            int b_first = 0;
-#pragma unroll
-            for (int i = 1; i < kMaxBatches; i++)
-                if (i < job.n_batches && fu2 >= job.batch[i].first) { b_out = job.batch[i].out; b_results = job.batch[i].results; b_first = job.batch[i].first; }
-            outp = b_out + (size_t)(fu2 - b_first) * job.out_stride;
-            b_results += fu2 - b_first;
+            outp = job.batch[0].out + (size_t)fl * job.out_stride;
+            b_results = job.batch[0].results + fl;
+            if (job.n_batches > 1) {
+                BatchPtr bt = batch_table();
+                outp = bt[bi].out + (size_t)fl * job.out_stride;
+                b_results = bt[bi].results + fl;
+            }
         }
 
         if (scale >= 64 || bad_budget) {
@@ -1926,6 +1960,23 @@ __global__ __launch_bounds__(64) void mdec_fdct_probe_kernel(const int16_t* in, 
 
 }  // namespace
 
+// The drop-in's one-frame-per-call pattern (encode_frame_bs, mdec.c:580; filefmt.c:643): the frame is copied from page-locked
+// host memory the device can see into HBM by a kernel of its own -- every lane one 16-byte load, all in flight at once -- instead
+// of a DMA-engine copy, whose start-up costs more than moving 115 KB does.  bytes is a multiple of 16.
+namespace {
+__global__ __launch_bounds__(256) void mdec_stage_in_kernel(const uint4* src, uint4* dst, int n16) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n16) dst[i] = src[i];
+}
+}  // namespace
+extern "C" hipError_t psxhip_mdec_stage_in_launch(const void* src_mapped, void* d_dst, size_t bytes, void* stream) {
+    const int n16 = (int)(bytes >> 4);
+    if (n16 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mdec_stage_in_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_mapped,
+                       (uint4*)d_dst, n16);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t psxhip_mdec_fdct_launch(const int16_t* d_in, int16_t* d_out, int n_blocks, void* stream) {
     if (n_blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(mdec_fdct_probe_kernel, dim3((unsigned)((n_blocks + 5) / 6)), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_blocks);
@@ -2001,9 +2052,10 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
         job.batch[i].out = a->batches[i].d_out;
         job.batch[i].results = a->batches[i].d_results;
         job.batch[i].max_sizes = a->batches[i].d_frame_max_sizes;
-        job.batch[i].first = first;
+        job.first[i] = first;
         first += a->batches[i].n_frames;
     }
+    for (int i = a->n_batches; i < kMaxBatches; i++) job.first[i] = 0x7FFFFFFF;
     job.frame_stride = a->frame_stride;
     job.width = a->width;
     job.height = a->height;

@@ -103,6 +103,14 @@ struct psxhip_mdec_ctx {
     hipStream_t stream2;             // chunks alternate between the two streams (and the two launch lanes): copies and kernels of neighbouring chunks overlap
     int cap_frames;                   // frames per chunk the buffers hold
     size_t cap_out_stride;
+    // the one-frame-per-call pattern (encode_frame_bs): one page-locked, device-visible block [frame | output row | result] and a
+    // frame-sized device buffer; a call is a CPU copy in, two launches (stage-in, encode -- which writes the host block itself), a
+    // wait, a CPU copy out
+    uint8_t* h_call;                  // host address
+    uint8_t* d_call;                  // the same block as the device addresses it
+    uint8_t* d_call_frame;
+    size_t call_out_off, call_res_off;
+    bool call_disabled;
 };
 
 namespace {
@@ -291,6 +299,8 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (c->d_order_large) (void)hipFree(c->d_order_large);
     if (c->d_stats) (void)hipFree(c->d_stats);
     psxhip_mdec_free_staging(c);
+    if (c->h_call) (void)hipHostFree(c->h_call);
+    if (c->d_call_frame) (void)hipFree(c->d_call_frame);
     for (int b = 0; b < 2; b++)
         if (c->chunk_done[b]) (void)hipEventDestroy(c->chunk_done[b]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -576,6 +586,46 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
         return PSXHIP_EINVAL;
     }
     const size_t dstride = ((size_t)max_size + 3) & ~(size_t)3;
+    if (n_frames == 1 && !c->call_disabled) {
+        // ---- one frame per call, the reference's own pattern (filefmt.c:643): see the context's h_call
+        if (!c->h_call) {
+            const size_t fpad = (fsz + 15) & ~(size_t)15, opad = ((size_t)c->max_frame_size + 15) & ~(size_t)15;
+            void* dp = nullptr;
+            if (getenv("PSXHIP_NO_PERCALL_PATH") ||
+                hipHostMalloc((void**)&c->h_call, fpad + opad + 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+                hipHostGetDevicePointer(&dp, c->h_call, 0) != hipSuccess || hipMalloc((void**)&c->d_call_frame, fpad) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c->h_call) (void)hipHostFree(c->h_call);
+                c->h_call = nullptr;
+                c->call_disabled = true;
+            } else {
+                c->d_call = (uint8_t*)dp;
+                c->call_out_off = fpad;
+                c->call_res_off = fpad + opad;
+            }
+        }
+        if (c->h_call) {
+            if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+            const size_t fpad = c->call_out_off;
+            memcpy(c->h_call, frames, fsz);
+            HIP_TRY(psxhip_mdec_stage_in_launch(c->d_call, c->d_call_frame, fpad, c->stream), PSXHIP_EDEVICE);
+            psxhip_mdec_batch_t bd;
+            bd.d_frames = c->d_call_frame; bd.n_frames = 1; bd.reserved = 0; bd.d_frame_max_sizes = nullptr;
+            bd.d_out = c->d_call + c->call_out_off; bd.d_results = (psxhip_mdec_result_t*)(c->d_call + c->call_res_off);
+            const int one = frame_max_sizes ? frame_max_sizes[0] : uniform_max_size;
+            if (dstride > (size_t)one) memset(c->h_call + c->call_out_off + one, 0, dstride - (size_t)one);   // (a row wider than the frame's own budget reads as zero there)
+            int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+            memcpy(out, c->h_call + c->call_out_off, (size_t)max_size);
+            memcpy(results, c->h_call + c->call_res_off, sizeof(psxhip_mdec_result_t));
+            if (results[0].quant_scale >= 64) {
+                psxhip_set_error("frame %d does not fit %d bytes at any quant scale", 0, one);
+                return PSXHIP_ENOFIT;
+            }
+            return PSXHIP_OK;
+        }
+    }
     // chunk: most of a GPU-load of frames -- small enough that a 1000-frame call already pipelines staging, DMA and kernel
     // over three chunks (353 k frames/s against 269 k with 1024-frame chunks), large enough for launches to stay efficient
     // (tools/gpu_chunk_sweep.py)

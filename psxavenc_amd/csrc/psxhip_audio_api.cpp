@@ -81,9 +81,67 @@ struct DevBuf {
     template <typename T> T* as() { return (T*)p; }
 };
 
+// The per-call fast path (the reference calls psx_audio_spu_encode once per 28 samples and psx_audio_xa_encode once per sector,
+// filefmt.c:243,184): one page-locked, device-visible block per host thread -- samples in, blocks / sectors and states out -- and
+// one stream.  A call is: copy the samples in (CPU), ONE launch (two for XA: chains, sector assembly), wait, copy the result out.
+struct CallScratch {
+    static constexpr size_t kIn = 32 << 10, kOut = 16 << 10, kStates = 256;
+    uint8_t* h = nullptr;       // [kIn samples | kOut blocks or sectors | kStates]
+    uint8_t* d = nullptr;       // the same block as the device addresses it
+    hipStream_t stream = nullptr;
+    int device = -1;
+    bool disabled = false;
+    void release() {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (h) (void)hipHostFree(h);
+        h = nullptr;
+        stream = nullptr;
+        device = -1;
+    }
+    ~CallScratch() { release(); }
+    bool ready(int dev) {
+        if (disabled) return false;
+        if (h && device == dev) return true;
+        release();
+        if (getenv("PSXHIP_NO_PERCALL_PATH")) { disabled = true; return false; }      // experiments / A-B measurements
+        if (hipHostMalloc((void**)&h, kIn + kOut + kStates, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            h = nullptr;
+            return false;
+        }
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess || !dp) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            h = nullptr;
+            return false;
+        }
+        d = (uint8_t*)dp;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            h = nullptr;
+            stream = nullptr;
+            return false;
+        }
+        device = dev;
+        return true;
+    }
+    int16_t* in() { return (int16_t*)h; }
+    uint8_t* out() { return h + kIn; }
+    psxhip_adpcm_state_t* states() { return (psxhip_adpcm_state_t*)(h + kIn + kOut); }
+    const int16_t* d_in() { return (const int16_t*)d; }
+    uint8_t* d_out() { return d + kIn; }
+    psxhip_adpcm_state_t* d_states() { return (psxhip_adpcm_state_t*)(d + kIn + kOut); }
+};
+thread_local CallScratch g_call;
+
 }  // namespace
 
-extern "C" void psxhip_release_scratch(void) { g_pool.release(); }
+extern "C" void psxhip_release_scratch(void) {
+    g_pool.release();
+    g_call.release();
+}
 
 extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples, int n_streams, int64_t stream_stride,
                                               int pitch, int samples_per_stream, psxhip_adpcm_state_t* states,
@@ -102,6 +160,43 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     }
     int rc = psxhip_ensure_device(device);
     if (rc) return rc;
+
+    // ---- the reference's call pattern (a few streams, a few blocks): one launch, no copies (see CallScratch)
+    if (n_streams <= 4 && n_units < kChunkedThreshold && (size_t)n_streams * ((size_t)n_units * 28 + 8) <= (size_t)psxhip_adpcm_call_stage_max() &&
+        (size_t)n_streams * bytes <= CallScratch::kOut && g_call.ready(device)) {
+        psxhip_adpcm_call_t a;
+        memset(&a, 0, sizeof a);
+        const size_t row = ((size_t)n_units * 28 + 7) & ~(size_t)7;      // staged row per stream: pitch 1, zero-padded to whole units
+        int16_t* in = g_call.in();
+        for (int i = 0; i < n_streams; i++) {
+            const int16_t* src = samples + (n_streams == 1 ? 0 : (size_t)i * (size_t)stream_stride);
+            int16_t* dst = in + (size_t)i * row;
+            if (pitch == 1) memcpy(dst, src, (size_t)samples_per_stream * sizeof(int16_t));
+            else for (int k = 0; k < samples_per_stream; k++) dst[k] = src[(size_t)k * pitch];
+            memset(dst + samples_per_stream, 0, (row - (size_t)samples_per_stream) * sizeof(int16_t));
+            a.chains[i].sample_offset = (int64_t)i * (int64_t)row;
+            a.chains[i].pitch = 1;
+            a.chains[i].sample_limit = samples_per_stream;
+            a.chains[i].n_units = n_units;
+            a.chains[i].unit_stride = 1;
+            a.unit_base[i] = i * n_units;
+            a.states_in[i] = states[i];
+        }
+        a.samples = g_call.d_in();
+        a.stage_elems = (int)(row * n_streams);
+        a.n_chains = n_streams;
+        a.filter_count = 5;
+        a.bits = 4;
+        a.states_out = g_call.d_states();
+        a.spu_out = g_call.d_out();
+        HIP_TRY(psxhip_adpcm_call_launch(&a, g_call.stream), PSXHIP_EDEVICE);
+        HIP_TRY(hipStreamSynchronize(g_call.stream), PSXHIP_EDEVICE);
+        for (int i = 0; i < n_streams; i++) {
+            memcpy(out + (size_t)i * (size_t)out_stride, g_call.out() + (size_t)i * bytes, (size_t)bytes);
+            states[i] = g_call.states()[i];
+        }
+        return bytes;
+    }
 
     const size_t per = (size_t)samples_per_stream * pitch;          // device row stride (elements)
     // the reference reads samples[i * pitch] for i < n (adpcm.c:65,110): only (n - 1) * pitch + 1 elements of a
@@ -196,6 +291,46 @@ extern "C" int psxhip_xa_encode_streams_host_flags(int device, int format, int s
     const int units_per_chain = units_per_stream / ch;
     const size_t per = (size_t)total;
     if (n_streams == 1) stream_stride = (int64_t)per;             // a single stream needs no stride
+    // ---- the reference's call pattern (one stream, a sector or two per call, filefmt.c:184,476-491): chains + assembly, two
+    //      launches, no copies (see CallScratch)
+    if (n_streams == 1 && sectors <= 6 && ((per + 7) & ~(size_t)7) <= (size_t)psxhip_adpcm_call_stage_max() && (size_t)bytes <= CallScratch::kOut &&
+        g_call.ready(device)) {
+        g_pool_device = device;
+        DevBuf d_u(4);
+        HIP_TRY(d_u.alloc((size_t)units_per_stream * PSXHIP_ADPCM_RECORD_BYTES), PSXHIP_ENOMEM);
+        psxhip_adpcm_call_t a;
+        memset(&a, 0, sizeof a);
+        const size_t row = (per + 7) & ~(size_t)7;
+        memcpy(g_call.in(), samples, per * sizeof(int16_t));
+        memset(g_call.in() + per, 0, (row - per) * sizeof(int16_t));
+        for (int c = 0; c < ch; c++) {
+            a.chains[c].sample_offset = c;
+            a.chains[c].pitch = ch;
+            a.chains[c].sample_limit = samples_per_stream;
+            a.chains[c].n_units = units_per_chain;
+            a.chains[c].unit_stride = ch;
+            a.unit_base[c] = c;
+            a.states_in[c] = states[c];
+        }
+        a.samples = g_call.d_in();
+        a.stage_elems = (int)row;
+        a.n_chains = ch;
+        a.filter_count = 4;
+        a.bits = bits;
+        a.states_out = g_call.d_states();
+        a.units = d_u.as<uint8_t>();
+        uint32_t eof_bits = 0;
+        for (int k = 0; k < sectors; k++)
+            if (eof_flags ? eof_flags[k] != 0 : (finalize && k == sectors - 1)) eof_bits |= 1u << k;
+        HIP_TRY(psxhip_adpcm_call_launch(&a, g_call.stream), PSXHIP_EDEVICE);
+        rc = psxhip_xa_assemble_device_bits(device, d_u.as<uint8_t>(), sectors, format, stereo, frequency, bits, file_number, channel_number,
+                                            lbas ? lbas[0] : 0, nullptr, eof_bits, g_call.d_out(), g_call.stream);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(g_call.stream), PSXHIP_EDEVICE);
+        memcpy(out, g_call.out(), (size_t)bytes);
+        for (int c = 0; c < ch; c++) states[c] = g_call.states()[c];
+        return bytes;
+    }
     std::vector<psxhip_adpcm_chain_t> chains((size_t)n_streams * ch);
     std::vector<int32_t> base((size_t)n_streams * ch);
     for (int i = 0; i < n_streams; i++)

@@ -45,6 +45,7 @@ hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int cap);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
+hipError_t psxhip_mdec_stage_in_launch(const void *src_mapped, void *d_dst, size_t bytes, void *stream);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
 
 int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t *ctx, const uint8_t *frames, int n_frames,
@@ -55,6 +56,25 @@ int psxhip_xa_encode_streams_host_flags(int device, int format, int stereo, int 
                                         int channel_number, const int16_t *samples, int n_streams, int64_t stream_stride,
                                         int samples_per_stream, const int32_t *lbas, psxhip_adpcm_state_t *states,
                                         uint8_t *out, int64_t out_stride, int finalize, const uint8_t *eof_flags);
+
+/* one launch for the reference's per-call pattern (adpcm_call_kernel): up to four chains, descriptors and start states in the
+ * kernel arguments, samples read from device-visible (page-locked host) memory */
+typedef struct {
+	const int16_t *samples;
+	int stage_elems;                     /* > 0: elements (multiple of 8, <= psxhip_adpcm_call_stage_max()) staged in LDS first */
+	psxhip_adpcm_chain_t chains[4];
+	psxhip_adpcm_state_t states_in[4];
+	int32_t unit_base[4];
+	int n_chains, filter_count, bits;
+	psxhip_adpcm_state_t *states_out;    /* [n_chains] */
+	uint8_t *units;                      /* 32-byte records, or NULL when spu_out is given */
+	uint8_t *spu_out;                    /* packed 16-byte SPU blocks */
+} psxhip_adpcm_call_t;
+hipError_t psxhip_adpcm_call_launch(const psxhip_adpcm_call_t *a, void *stream);
+int psxhip_adpcm_call_stage_max(void);
+int psxhip_xa_assemble_device_bits(int device, const uint8_t *d_units, int n_sectors, int format, int stereo, int frequency, int bits,
+                                   int file_number, int channel_number, int first_lba, const uint8_t *d_eof_flags, uint32_t eof_bits,
+                                   uint8_t *d_out, void *stream);
 
 void psxhip_set_error(const char *fmt, ...);
 

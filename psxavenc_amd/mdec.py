@@ -111,6 +111,58 @@ class MdecEncoder:
         return d_out, d_results
 
 
+    def encode_batches_device(self, batches, frame_max_size, stream=None):
+        """psxhip_mdec_encode_batches_device: several batches, ONE launch.  batches: sequence of (d_frames, d_out, d_results) or
+        (d_frames, d_out, d_results, d_sizes) CUDA tensors with common row strides; frame_max_size: the uniform budget."""
+        assert torch is not None and len(batches) > 0
+        arr = (MdecBatch * len(batches))()
+        fstride = ostride = None
+        for i, b in enumerate(batches):
+            d_frames, d_out, d_res = b[0], b[1], b[2]
+            d_sizes = b[3] if len(b) > 3 else None
+            assert d_frames.is_cuda and d_frames.dtype == torch.uint8 and d_out.dtype == torch.uint8 and d_res.dtype == torch.int32
+            n = d_frames.shape[0]
+            assert d_out.shape[0] == n and d_res.shape[0] == n
+            if n:
+                fstride = d_frames.stride(0) if fstride is None else fstride
+                ostride = d_out.stride(0) if ostride is None else ostride
+                assert d_frames.stride(0) == fstride and d_out.stride(0) == ostride, "batches share their row strides"
+            arr[i] = MdecBatch(d_frames.data_ptr(), n, 0, d_sizes.data_ptr() if d_sizes is not None else None, d_out.data_ptr(), d_res.data_ptr())
+        st = stream if stream is not None else torch.cuda.current_stream(batches[0][0].device)
+        L = _lib.lib()
+        L.psxhip_mdec_encode_batches_device.argtypes = [C.c_void_p, C.POINTER(MdecBatch), C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+        _lib.check(L.psxhip_mdec_encode_batches_device(self._h, arr, len(batches), fstride or self.frame_bytes, int(frame_max_size),
+                                                       ostride or ((int(frame_max_size) + 3) & ~3), st.cuda_stream))
+
+    def set_lanes(self, lanes):
+        """psxhip_mdec_set_lanes: 2 = consecutive launches of this context on one caller stream may overlap; the results of the
+        LAST launch are ordered into the stream by the next encode call or by fence()"""
+        L = _lib.lib()
+        L.psxhip_mdec_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        _lib.check(L.psxhip_mdec_set_lanes(self._h, int(lanes)))
+
+    def fence(self, stream=None):
+        """psxhip_mdec_fence: order `stream` behind every launch of this context issued so far"""
+        L = _lib.lib()
+        L.psxhip_mdec_fence.argtypes = [C.c_void_p, C.c_void_p]
+        st = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", self.device))
+        _lib.check(L.psxhip_mdec_fence(self._h, st.cuda_stream))
+
+    def watchdog(self):
+        """psxhip_mdec_watchdog: frames the retry queue's watchdog gave up (0 on a healthy device); synchronises"""
+        L = _lib.lib()
+        L.psxhip_mdec_watchdog.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        lost = C.c_uint(0)
+        _lib.check(L.psxhip_mdec_watchdog(self._h, C.byref(lost)))
+        return int(lost.value)
+
+
+class MdecBatch(C.Structure):
+    """psxhip_mdec_batch_t"""
+    _fields_ = [("d_frames", C.c_void_p), ("n_frames", C.c_int32), ("reserved", C.c_int32), ("d_frame_max_sizes", C.c_void_p),
+                ("d_out", C.c_void_p), ("d_results", C.c_void_p)]
+
+
 def register_host(a):
     """Page-lock a numpy array's memory (psxhip_host_register): the host entry points then move it by DMA, no staging copy."""
     L = _lib.lib()

@@ -507,3 +507,43 @@ def test_xacd_config5_full_size_every_sector_against_the_reference():
         for k in range(0, n_sectors, 337):
             edc = O.lib().orc_edc_crc32(O.ptr(np.ascontiguousarray(g[k, 16:0x92C]), O.u8p), 0x92C - 16)
             assert int.from_bytes(g[k, 0x92C:0x930].tobytes(), "little") == edc
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_per_call_path_speculates_inside_one_launch_and_equals_the_serial_encode(kind):
+    """The reference's call pattern (filefmt.c:184,243,335: one sector / 28 samples / one SPUI chunk per call) is ONE launch
+    (adpcm_call_kernel), whose spare rows speculate on later segments of the chain and whose result must be the serial encode's
+    whatever the guesses: every signal class (tones never fall into the guessed state, silence ties, noise saturates), chain
+    lengths around the speculation limits, 1-4 streams, carried states, XA 4/8-bit mono/stereo one and two sectors per call."""
+    from psxavenc_amd import adpcm
+    # SPU: one chain -> four segments; 2 chains -> two each; 3, 4 chains -> none
+    for n_streams, units in [(1, 1), (1, 23), (1, 24), (1, 25), (1, 97), (1, 128), (1, 290), (2, 40), (2, 73), (2, 130), (3, 60), (4, 70)]:
+        n = units * 28 - (5 if units % 3 == 1 and units > 1 else 0)            # ragged tails too
+        pcm = np.stack([O.synth_pcm(500 + kind, s, 7 * units, n, kind) for s in range(n_streams)])
+        st = np.array([[(-1) ** s * 300 * s, 17 * s] for s in range(n_streams)], np.int32)
+        st0 = st.copy()
+        got = adpcm.spu_encode_streams(pcm, states=st)
+        for s in range(n_streams):
+            want, ost = O.spu_encode(pcm[s], state=O.Chan(int(st0[s, 0]), int(st0[s, 1])))
+            assert np.array_equal(got[s], want), (kind, n_streams, units, s)
+            assert (int(st[s, 0]), int(st[s, 1])) == (ost.prev1, ost.prev2), (kind, n_streams, units, s)
+    # XA: sector by sector and two sectors at a time, state carried
+    for stereo, bits, per_call in [(True, 4, 1), (True, 4, 2), (False, 4, 1), (True, 8, 1), (True, 8, 3), (False, 8, 2)]:
+        s = adpcm.XaSettings(adpcm.PSX_AUDIO_XA_FORMAT_XACD, stereo, 37800, bits, 1, 0)
+        os_ = O.XaSettings(1, int(stereo), 37800, bits, 1, 0)
+        sps = adpcm.xa_get_samples_per_sector(s)
+        calls = 3
+        n = sps * per_call * calls - 333                                        # the last call is short
+        pcm = stereo_pad(kind, n, 600 + kind) if stereo else mono_pad(kind, n, 600 + kind)
+        ch = 2 if stereo else 1
+        st, ost = adpcm.EncoderState(), O.State()
+        for k in range(calls):
+            first = k * sps * per_call
+            cnt = min(sps * per_call, n - first)
+            chunk = pcm[ch * first:]
+            got = adpcm.psx_audio_xa_encode(s, st, chunk, cnt, k * per_call)
+            want, ost = O.xa_encode(os_, chunk, cnt, lba=k * per_call, state=ost)
+            assert np.array_equal(got, want), (kind, stereo, bits, per_call, k)
+        assert (st.left.prev1, st.left.prev2) == (ost.left.prev1, ost.left.prev2)
+        if stereo:
+            assert (st.right.prev1, st.right.prev2) == (ost.right.prev1, ost.right.prev2)

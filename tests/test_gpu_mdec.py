@@ -634,3 +634,106 @@ def test_production_shapes_in_one_launch(torch_cuda, w, h, budget, n, amp, tile,
         assert rc2 == 0 and version == 3 and scale == res[k, 0]
         assert res[k, 1] == ((8 + 2 * ((nbits + 15) // 16) + 3) & ~3)
     enc.close()
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_batches_in_one_launch_equal_one_call_per_batch(torch_cuda, codec):
+    """psxhip_mdec_encode_batches_device: the frames of several batches drawn from ONE ticket counter (no launch boundary between
+    the batches) -- bytes and results must be those of one call per batch, and of the oracle.  Sizes either side of the shapes'
+    limits, an empty batch, a one-frame batch, per-frame budgets in some batches, and more batches than one launch carries."""
+    torch = torch_cuda
+    w, h, budget = 320, 240, 8192
+    sizes = [700, 0, 37, 600, 1, 300, 2, 129, 64, 5, 90]          # 11 batches: two launches (8 + 3)
+    rng = np.random.default_rng(77 + codec)
+    enc, ref = encoder(codec, w, h, budget), encoder(codec, w, h, budget)
+    ostride = (budget + 3) & ~3
+    batches, wants = [], []
+    for i, n in enumerate(sizes):
+        fr = O.synth_frames(w, h, n, seed=900 + i, amp=(4, 8, 16)[i % 3], first=17 * i) if n else np.zeros((0, w * h * 3 // 2), np.uint8)
+        d = torch.from_numpy(fr).to("cuda:0")
+        d_out = torch.full((n, ostride), 0xAB, dtype=torch.uint8, device="cuda:0")
+        d_res = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+        d_sz = None
+        if i % 4 == 3 and n:
+            bd = rng.integers(4096, budget + 1, n).astype(np.int32)
+            d_sz = torch.from_numpy(bd).to("cuda:0")
+            d_out.zero_()                 # (rows of a per-frame-budget batch are only written up to each frame's own budget)
+        batches.append((d, d_out, d_res) + ((d_sz,) if d_sz is not None else ()))
+        if n:
+            w_out, w_res = ref.encode_frames_device(d, d_sz if d_sz is not None else budget)
+            torch.cuda.synchronize()
+            wants.append((w_out.cpu().numpy(), w_res.cpu().numpy(), None if d_sz is None else bd))
+            want, want_res, rc = O.mdec_encode(codec, w, h, fr[:8], budget if d_sz is None else bd[:8], **({} if d_sz is None else {"stride": budget}))
+            assert rc == 0 and np.array_equal(wants[-1][1][:8], want_res)
+        else:
+            wants.append(None)
+    enc.encode_batches_device(batches, budget)
+    torch.cuda.synchronize()
+    for i, (b, wnt) in enumerate(zip(batches, wants)):
+        if wnt is None:
+            continue
+        got, got_res = b[1].cpu().numpy(), b[2].cpu().numpy()
+        assert np.array_equal(got_res, wnt[1]), "batch %d results" % i
+        if wnt[2] is None:
+            assert np.array_equal(got, wnt[0]), "batch %d bytes" % i
+        else:
+            for k in range(got.shape[0]):
+                assert np.array_equal(got[k, :wnt[2][k]], wnt[0][k, :wnt[2][k]]), "batch %d frame %d" % (i, k)
+    assert enc.watchdog() == 0
+    # argument vetting: a NULL output in a non-empty batch, and a misaligned pointer
+    from psxavenc_amd import _lib
+    bad = list(batches[:2]) + [(batches[2][0], batches[2][1][:, 1:], batches[2][2])]
+    with pytest.raises((_lib.PsxHipError, AssertionError)):
+        enc.encode_batches_device(bad, budget)
+    enc.close()
+    ref.close()
+
+
+def test_two_launch_lanes_overlap_launches_of_one_context_same_bytes(torch_cuda):
+    """psxhip_mdec_set_lanes(2): the in-order caller of filefmt.c:641-647 with double buffering -- inputs are produced ON the
+    caller's stream right before each call (dependent launches), outputs are read on the stream one call later (results lag one
+    call), the last one after psxhip_mdec_fence.  Every byte equals the one-lane encode; interleaved with independent launches."""
+    torch = torch_cuda
+    w, h, budget, n = 320, 240, 8192, 700
+    K = 9
+    src = [torch.from_numpy(O.synth_frames(w, h, n, seed=300 + k, amp=(4, 8)[k & 1], first=k * n)).to("cuda:0") for k in range(K)]
+    one = encoder(0, w, h, budget)
+    wants = []
+    for k in range(K):
+        o, r = one.encode_frames_device(src[k], budget)
+        torch.cuda.synchronize()
+        wants.append((o.cpu().numpy(), r.cpu().numpy()))
+    want0, want0_res, rc = O.mdec_encode(0, w, h, src[0][:16].cpu().numpy(), budget)
+    assert rc == 0 and np.array_equal(wants[0][0][:16, :budget], want0)
+    one.close()
+    enc = encoder(0, w, h, budget)
+    enc.set_lanes(2)
+    ostride = (budget + 3) & ~3
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d_in = [torch.empty_like(src[0]) for _ in range(2)]
+        d_out = [torch.zeros((n, ostride), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        d_res = [torch.zeros((n, 4), dtype=torch.int32, device="cuda:0") for _ in range(3)]
+        snaps = []
+        for rep in range(3):
+            for k in range(K):
+                d_in[k & 1].copy_(src[k], non_blocking=True)                       # produced on the stream: the launch must wait for it
+                enc.encode_frames_device(d_in[k & 1], budget, d_out=d_out[k % 3], d_results=d_res[k % 3])
+                if k >= 1:                                                         # launch k-1 is ordered into the stream by call k
+                    snaps.append((k - 1, d_out[(k - 1) % 3].clone(), d_res[(k - 1) % 3].clone()))
+                if k == 4:                                                         # an independent launch of the same context in between
+                    enc.encode_frames_device(src[0], budget, d_out=d_out[(k + 1) % 3], d_results=d_res[(k + 1) % 3])
+                    enc.fence()
+                    snaps.append((0, d_out[(k + 1) % 3].clone(), d_res[(k + 1) % 3].clone()))
+            enc.fence()
+            snaps.append((K - 1, d_out[(K - 1) % 3].clone(), d_res[(K - 1) % 3].clone()))
+    s.synchronize()
+    for k, o, r in snaps:
+        assert np.array_equal(r.cpu().numpy(), wants[k][1]), "launch %d results" % k
+        assert np.array_equal(o.cpu().numpy(), wants[k][0]), "launch %d bytes" % k
+    assert enc.watchdog() == 0
+    enc.set_lanes(1)                 # back to plain stream order
+    o, r = enc.encode_frames_device(src[3], budget)
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), wants[3][0])
+    enc.close()
