@@ -32,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <string.h>
 
 #include "bs_vlc_lut.h"
@@ -49,6 +50,14 @@ constexpr int kTileStride = 72;   // int16 per block in the transpose tile: 6 bl
 constexpr int kZStride = 64;      // int16 per block in the coefficient tile: column-pass lane t stores its 8 outputs at bytes 16 t
 constexpr int kPilotMax = 4;      // scales evaluated per pilot round
 constexpr int kMaxTiles = 16;     // image tiles of 2048 dwords: budgets up to 128 KiB
+// profiling builds (-DPSX_EXP_STOP_AFTER=n, WRONG BYTES, every frame ends after its first pass): a macroblock's work stops after
+// 1 = ticket + pixel fetch, 2 = + DCT, 3 = + coefficient read and list build.  PMC differences between them and the product build
+// are where the instruction inventory in DESIGN.md comes from (tools/gpu_pmc_quick.sh, tools/build_variant.sh).
+#ifdef PSX_EXP_STOP_AFTER
+constexpr int kStopAfter = PSX_EXP_STOP_AFTER;
+#else
+constexpr int kStopAfter = 0;
+#endif
 constexpr uint32_t kNoMb = 0xFFFFu;   // pass order entry without a macroblock (the last round of tickets may be partial)
 constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
 // Frame tickets and the retry queue's state share one 64-bit word of the ticket buffer, in a cache line of its own: fresh-frame
@@ -110,8 +119,18 @@ struct FrameJob {
 // the batch table where it lies in the kernel argument segment (FrameJob is the kernel's only argument, `batch` its first member)
 typedef const BatchDesc __attribute__((address_space(4))) * BatchPtr;
 typedef const int __attribute__((address_space(4))) * FirstPtr;
+// n_batches, read where it is asked for (as a plain member the compiler kept "n_batches > 1" for the whole kernel -- as 0 / 1 in a
+// vector register it then spilled)
+#define PSX_BATCHES_MANY() (((FirstPtr)(batch_table() + kMaxBatches))[kMaxBatches] > 1)
 __device__ __forceinline__ BatchPtr batch_table() {
     BatchPtr p = (BatchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// the retry queue's slots, the address made where it is used (one thread, rarely): as a loop invariant the 64-bit address sat in
+// two vector registers -- or a scratch slot -- for the whole kernel
+__device__ __forceinline__ unsigned int* retry_slots(const FrameJob& job) {
+    unsigned int* p = job.retry;
     asm volatile("" : "+s"(p));
     return p;
 }
@@ -153,6 +172,8 @@ enum {
     S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
     S_HINT_BUDGET,      // ... and its budget
     S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
+    S_NEXT_DRAW,        // thread 0's ticket for the frame after next, parked here over the passes (it is a register from the draw to the start of the next frame's passes: the atomic's round trip hides behind a frame's work, and the passes have no register to spare)
+    S_PAD0,
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -242,6 +263,42 @@ __device__ __forceinline__ void fdct8_pk(uint32_t P0, uint32_t P1, uint32_t R0, 
     d[5] = dot2_k(D0, pk(C5_3, C5_2), dot2_k(D1, pk(C5_1, C5_0), rnd)) >> SH;
     d[3] = dot2_k(D0, pk(C3_3, C3_2), dot2_k(D1, pk(C3_1, C3_0), rnd)) >> SH;
     d[1] = dot2_k(D0, pk(C1_3, C1_2), dot2_k(D1, pk(C1_1, C1_0), rnd)) >> SH;
+}
+
+// The COLUMN pass with all eight outputs in ONE form: acc[i] such that out[i] = acc[i] >> 17, the rounding constant 2^16
+// included.  Outputs 0 and 4 -- (sum + 8) >> 4 in jfdctint -- are (8192 * sum + 2^16) >> 17: the same number (a factor of
+// 2^13 on numerator and denominator; |sum| <= 4 * 32640, so 8192 * sum stays below 2^31), which lets one register hold the
+// rounding constant for all eight chains and lets the caller take every output from the HIGH half of its accumulator:
+// (x >> 17) == ((x >> 16) >> 1), i.e. a byte permute that packs two high halves and one packed 16-bit shift per PAIR of
+// outputs -- 8 instructions for the eight outputs where eight 32-bit shifts and four permutes were 12.
+__device__ __forceinline__ void fdct8_col_acc(uint32_t P0, uint32_t P1, uint32_t R0, uint32_t R1, int (&a)[8]) {
+    constexpr int K_0_298 = 2446, K_0_390 = 3196, K_0_541 = 4433, K_0_765 = 6270, K_0_899 = 7373,
+                  K_1_175 = 9633, K_1_501 = 12299, K_1_847 = 15137, K_1_961 = 16069, K_2_053 = 16819,
+                  K_2_562 = 20995, K_3_072 = 25172;
+    constexpr int A = K_0_541 + K_0_765, B = K_0_541, C = K_0_541 - K_1_847;
+    constexpr int C7_0 = K_0_298 - K_0_899 - K_1_961 + K_1_175, C7_1 = K_1_175, C7_2 = K_1_175 - K_1_961, C7_3 = K_1_175 - K_0_899;
+    constexpr int C5_0 = K_1_175, C5_1 = K_2_053 - K_2_562 - K_0_390 + K_1_175, C5_2 = K_1_175 - K_2_562, C5_3 = K_1_175 - K_0_390;
+    constexpr int C3_0 = K_1_175 - K_1_961, C3_1 = K_1_175 - K_2_562, C3_2 = K_3_072 - K_2_562 - K_1_961 + K_1_175, C3_3 = K_1_175;
+    constexpr int C1_0 = K_1_175 - K_0_899, C1_1 = K_1_175 - K_0_390, C1_2 = K_1_175, C1_3 = K_1_501 - K_0_899 - K_0_390 + K_1_175;
+    constexpr int E = 8192;
+    const uint32_t S0 = pk_add(P0, R0);   // (s07, s16)
+    const uint32_t S1 = pk_add(P1, R1);   // (s25, s34)
+    const uint32_t D0 = pk_sub(P0, R0);   // (o3, o2)
+    const uint32_t D1 = pk_sub(P1, R1);   // (o1, o0)
+    const int rnd = 1 << 16;
+    a[0] = dot2_k(S0, pk(E, E), dot2_k(S1, pk(E, E), rnd));
+    a[4] = dot2_k(S0, pk(E, -E), dot2_k(S1, pk(-E, E), rnd));
+    a[2] = dot2_k(S0, pk(A, B), dot2_k(S1, pk(-B, -A), rnd));
+    a[6] = dot2_k(S0, pk(B, C), dot2_k(S1, pk(-C, -B), rnd));
+    a[7] = dot2_k(D0, pk(C7_3, C7_2), dot2_k(D1, pk(C7_1, C7_0), rnd));
+    a[5] = dot2_k(D0, pk(C5_3, C5_2), dot2_k(D1, pk(C5_1, C5_0), rnd));
+    a[3] = dot2_k(D0, pk(C3_3, C3_2), dot2_k(D1, pk(C3_1, C3_0), rnd));
+    a[1] = dot2_k(D0, pk(C1_3, C1_2), dot2_k(D1, pk(C1_1, C1_0), rnd));
+}
+// (hi >> 17, lo >> 17) as packed int16 (lo in the low half): the two high halves side by side, each shifted once more
+__device__ __forceinline__ uint32_t pack_sh17(int hi, int lo) {
+    const uint32_t p = __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060302u);
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, p) >> (s16x2){1, 1}));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,10 +402,10 @@ __device__ __forceinline__ void wave_sync() {
 
 // DC: divisor is always 16 (mdec.c:671), clamp to [-512, 510] (mdec.c:260-267).
 __device__ __forceinline__ int quant_dc(int c0) {
-    const int a = c0 < 0 ? -c0 : c0;
-    const int q = (a + 8) >> 4;
-    const int v = c0 < 0 ? -q : q;
-    return v < -512 ? -512 : (v > 510 ? 510 : v);
+    // sgn(c0) * ((|c0| + 8) >> 4)  ==  (c0 + 8 + (c0 >> 31)) >> 4  (round half away from zero; checked over the whole range
+    // in tests/test_mdec_oracle.py::test_integer_identities_of_the_kernel)
+    const int q = (c0 + 8 + (c0 >> 31)) >> 4;
+    return q < -512 ? -512 : (q > 510 ? 510 : q);
 }
 
 struct Lds {
@@ -372,41 +429,42 @@ struct Lds {
 };
 
 static_assert(sizeof(MdecSearch) == 56 && (S_SEARCH % 2) == 0, "MdecSearch lives in scalars[S_SEARCH..+14)");
-static_assert(offsetof(FrameJob, batch) == 0 && offsetof(FrameJob, first) == sizeof(BatchDesc) * kMaxBatches, "batch_table() reads the table at the start of the kernel argument segment");
+static_assert(offsetof(FrameJob, batch) == 0 && offsetof(FrameJob, first) == sizeof(BatchDesc) * kMaxBatches && offsetof(FrameJob, n_batches) == sizeof(BatchDesc) * kMaxBatches + 4 * kMaxBatches, "batch_table() reads the table at the start of the kernel argument segment");
 constexpr int kWaveTileBytes = ((6 * kTileStride * 2 + 6 * kZStride * 2) + 15) / 16 * 16;   // transpose tile + coefficient tile
 static_assert(kWaveTileBytes >= 384 * 4, "the per-wave code list (384 entries) aliases the tiles");
 
 __host__ __device__ inline int dc_chunks(int nmb) { return 2 * ((nmb + 63) >> 6) + ((4 * nmb + 63) >> 6); }
 
-__host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_words, int waves) {
+// LDS layout: everything whose size is known at compile time (given the workgroup shape) comes FIRST, at constant offsets --
+// the compiler folds those addresses into the instructions' offset fields, where run-time offsets each took a scalar register
+// (sixteen base addresses in a kernel that spills a hundred scalar registers) -- then the arrays sized by the geometry.
+__host__ __device__ constexpr size_t lds_fixed_bytes(int waves) {
     size_t b = 0;
+    b += (size_t)S_COUNT * 4;             // scalars
+    b += BS_LUT_SIZE * 2;                 // ac_len16
+    b = (b + 3) & ~(size_t)3;
+    b += BS_LUT_SIZE * 4;                 // ac_code
+    b += 32;                              // dc tables
+    b = (b + 15) & ~(size_t)15;
+    b += 2 * 64 * 16 + 2 * 64;            // per-lane constant tables, scan-position table, quant matrix
+    b += (size_t)waves * kWaveTileBytes;  // tiles
+    return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t lds_bytes(int nmb, int out_words, int stg_words, int waves) {
+    size_t b = lds_fixed_bytes(waves);
     b += (size_t)out_words * 4;
     b += (size_t)stg_words * 4;
     b += (size_t)nmb * 4;         // rec
     b += (size_t)nmb * 4;         // mb_off
     b += (size_t)dc_chunks(nmb) * 16;   // dc_fn
     b += (size_t)nmb * 6 * 2;     // dcv
-    b = (b + 3) & ~(size_t)3;
-    b += BS_LUT_SIZE * 2;         // ac_len16
-    b = (b + 3) & ~(size_t)3;
-    b += BS_LUT_SIZE * 4;         // ac_code
-    b += 32;                      // dc tables
-    b = (b + 15) & ~(size_t)15;
-    b += 2 * 64 * 16 + 2 * 64;    // per-lane constant tables, scan-position table, quant matrix
-    b += (size_t)waves * kWaveTileBytes;
-    b += (size_t)S_COUNT * 4;
     return (b + 15) & ~(size_t)15;
 }
-
-__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg_words, int waves) {
+template <int WAVES>
+__device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg_words) {
     Lds L;
     size_t b = 0;
-    L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
-    L.stg = (uint32_t*)(base + b);        b += (size_t)stg_words * 4;
-    L.rec = (uint32_t*)(base + b);        b += (size_t)nmb * 4;
-    L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
-    L.dc_fn = (int*)(base + b);           b += (size_t)dc_chunks(nmb) * 16;
-    L.dcv = (int16_t*)(base + b);         b += (size_t)nmb * 6 * 2;               b = (b + 3) & ~(size_t)3;
+    L.scalars = (int*)(base + b);         b += (size_t)S_COUNT * 4;
     L.ac_len16 = (uint16_t*)(base + b);   b += BS_LUT_SIZE * 2;                    b = (b + 3) & ~(size_t)3;
     L.ac_code = (uint32_t*)(base + b);    b += BS_LUT_SIZE * 4;
     L.dc_plen = (uint8_t*)(base + b);     b += 16;
@@ -415,8 +473,13 @@ __device__ __forceinline__ Lds carve(char* base, int nmb, int out_words, int stg
     L.tab_pix = (uint4*)(base + b);       b += 64 * 16;
     L.tab_nat = (uint8_t*)(base + b);     b += 64;
     L.qzz = (uint8_t*)(base + b);         b += 64;
-    L.tiles = (int16_t*)(base + b);       b += (size_t)waves * kWaveTileBytes;
-    L.scalars = (int*)(base + b);
+    L.tiles = (int16_t*)(base + b);       b += (size_t)WAVES * kWaveTileBytes;     b = (b + 15) & ~(size_t)15;
+    L.out = (uint32_t*)(base + b);        b += (size_t)out_words * 4;
+    L.stg = (uint32_t*)(base + b);        b += (size_t)stg_words * 4;
+    L.rec = (uint32_t*)(base + b);        b += (size_t)nmb * 4;
+    L.mb_off = (uint32_t*)(base + b);     b += (size_t)nmb * 4;
+    L.dc_fn = (int*)(base + b);           b += (size_t)dc_chunks(nmb) * 16;
+    L.dcv = (int16_t*)(base + b);
     return L;
 }
 
@@ -433,8 +496,7 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t pos, int len,
 // Per-lane constants of the AC path: lane k owns zig-zag position k.
 struct LaneConst {
     int quant;          // quant matrix entry at this zig-zag position
-    uint64_t below;     // mask of lanes below this one
-    int lane_m64;       // lane - 64
+    int lane;           // (masks and offsets derived from it are made where they are used: 80 registers)
     int zsrc;           // where this lane's scan position sits in a block of the coefficient tile
 };
 
@@ -466,8 +528,9 @@ __device__ __forceinline__ int quant_mag(float cf, const QuantK& k) {
 // number of zero coefficients between this lane and the previous non-zero one (bit 0 of the mask, the
 // DC slot, is the sentinel): lane - 1 - (63 - clz(mask below me))
 __device__ __forceinline__ int run_before(uint64_t nz_mask, const LaneConst& lc) {
-    const uint64_t prev = (nz_mask | 1ull) & lc.below;
-    return __clzll((long long)prev) + lc.lane_m64;
+    const int ln = in_loop(lc.lane);
+    const uint64_t prev = (nz_mask | 1ull) & ((1ull << ln) - 1ull);
+    return __clzll((long long)prev) + (ln - 64);
 }
 
 // index into the padded LUTs: row = min(|level|, MAX_LEVEL + 1), column = run (0..62).  Level 0 is row 0
@@ -608,7 +671,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     constexpr int kWavesPerGroup = WAVES;
     constexpr int kThreads = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds L = carve(smem, job.nmb, job.out_words, job.stg_words, WAVES);
+    const Lds L = carve<WAVES>(smem, job.nmb, job.out_words, job.stg_words);
 
     const int tid = (int)threadIdx.x;
     unsigned long long t_entry = 0, t_first = 0;
@@ -740,11 +803,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
-    auto end_of_frame = [&](int tid) {
+    auto end_of_frame = [&](int tid, bool parked = true) {
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE && tid != S_PUSHED) L.scalars[tid] = 0;
+        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE && tid != S_PUSHED && tid != S_NEXT_DRAW) L.scalars[tid] = 0;
         if (tid == 0) {
             // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
+            if (parked) next_draw = (unsigned)L.scalars[S_NEXT_DRAW];
             L.scalars[S_FRAME] = (int)(next_draw + gridDim.x);
             if (next_draw < fresh_draws) {
                 next_draw = draw_ticket(job);
@@ -762,6 +826,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_SHARED_HINT) L.scalars[tid] = 0;
     __syncthreads();
     for (;;) {
+        // thread- and lane-derived values (loop bases, masks, LDS addresses, even the predicate "thread 0") are re-derived per
+        // frame from an opaque copy of the thread index: hoisted out of the frame loop they would be spilled to scratch once per
+        // wavefront (4 KB each, 25 MB per 1000 frames at two frames per group)
+        int tid_f = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_f));
+        const int tid = tid_f;               // shadows the kernel-scope copy on purpose
         int f = L.scalars[S_FRAME];
         if (f >= job.n_frames) {
             // No fresh frame left for this group: frames that other groups handed on instead of running another pass over them
@@ -793,7 +863,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     // a group that has not started may be waiting for THIS group's place on a CU: then nobody waits
                     if (started < gridDim.x || looks >= job.retry_patience) {
                         if (h < (unsigned)job.retry_cap) {
-                            if (atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned) != kRetryEmpty) there = true;      // filled this very moment
+                            if (atomicCAS(&retry_slots(job)[h], (unsigned)in_loop((int)kRetryEmpty), (unsigned)in_loop((int)kRetryAbandoned)) != kRetryEmpty) there = true;      // filled this very moment
                             else atomicAdd(&job.ticket[1], 0x10000u);          // a note for the group that re-arms the queue
                         }
                         break;
@@ -809,17 +879,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     // bites for the host (psxhip_mdec_watchdog: non-zero = results of that launch are incomplete).
                     unsigned v = kRetryEmpty;
                     for (int looks = 0; v == kRetryEmpty && looks < (1 << 20); looks++) {
-                        v = queue_peek(&job.retry[h], looks);
+                        v = queue_peek(&retry_slots(job)[h], looks);
                         if (looks >= 4096) __builtin_amdgcn_s_sleep(32);
                     }
                     if (v == kRetryEmpty) {
-                        v = atomicCAS(&job.retry[h], kRetryEmpty, kRetryAbandoned);
+                        v = atomicCAS(&retry_slots(job)[h], (unsigned)in_loop((int)kRetryEmpty), (unsigned)in_loop((int)kRetryAbandoned));
                         if (v == kRetryEmpty) { atomicAdd(&job.ticket[3], 1u); atomicAdd(&job.ticket[1], 0x10000u); }
                     }
                     if (v != kRetryEmpty) {
                         L.scalars[S_FRAME] = (int)(v & 0xFFFFFFu);
                         got = (int)(v >> 24);
-                        job.retry[h] = kRetryEmpty;          // vacated for the next launch (nobody looks at it again in this one)
+                        retry_slots(job)[h] = (unsigned)in_loop((int)kRetryEmpty);          // vacated for the next launch (nobody looks at it again in this one)
                     }
                 }
                 L.scalars[S_RETRY] = got;
@@ -829,18 +899,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             f = L.scalars[S_FRAME];
         }
 
-        // thread- and lane-derived values (loop bases, masks, LDS addresses) are re-derived per frame from an opaque copy of
-        // the thread index: hoisted out of the frame loop they would be spilled to scratch once per wavefront (4 KB each,
-        // 25 MB per 1000 frames at two frames per group)
-        int tid_f = tid;
-        asm volatile("" : "+v"(tid_f));
-        const int tid = tid_f;               // shadows the kernel-scope copies on purpose
         const int lane = tid & 63;
         const int blk = lane >> 3, r8 = lane & 7;
         LaneConst lc;
         lc.quant = L.qzz[lane];
-        lc.below = (1ull << lane) - 1ull;
-        lc.lane_m64 = lane - 64;
+        lc.lane = lane;
         lc.zsrc = (int)L.tab_nat[lane];
         // Which batch the frame belongs to (wave-uniform: f comes from one LDS word).  The batch table is read from the kernel
         // argument segment WHERE it is needed, through a pointer the compiler cannot see through -- here for the input, again at
@@ -854,7 +917,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         fl = f;
         b_sizes = job.batch[0].max_sizes;                  // one batch (the common launch): plain kernel arguments, nothing to look up
         frame = job.batch[0].frames + (size_t)f * job.frame_stride;
-        if (job.n_batches > 1) {                           // (straight-line scalar code: a loop here cost the 12-wavefront shape two vector registers it does not have)
+        if (PSX_BATCHES_MANY()) {                           // (straight-line scalar code: a loop here cost the 12-wavefront shape two vector registers it does not have)
             BatchPtr bt = batch_table();
             FirstPtr ft = (FirstPtr)(bt + kMaxBatches);
 #pragma unroll
@@ -1104,17 +1167,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (lane < 48) {
                 // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
                 const uint4 q = *(const uint4*)&tileT[blk * kTileStride + r8 * 8];
-                fdct8_pk<true>(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
-                // -- column 0 holds the block's DC term in d[0].  v2: its quantised value (mdec.c:447-453) takes its place at
-                //    scan position 0 and travels with the block's DC slot in the code list.  v3: the DC codes come from the
-                //    pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated as an AC coefficient.
-                if (r8 == 0) d[0] = CODEC == 0 ? quant_dc(d[0]) : 0;
+                fdct8_col_acc(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+                // -- column 0 holds the block's DC term in d[0] (as an accumulator: value << 17).  v2: its quantised value
+                //    (mdec.c:447-453) takes its place at scan position 0 and travels with the block's DC slot in the code list.
+                //    v3: the DC codes come from the pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated
+                //    as an AC coefficient.
+                if (r8 == 0) d[0] = CODEC == 0 ? (int)((uint32_t)quant_dc(d[0] >> 17) << 17) : 0;
                 // the column's 8 outputs (rows 0..7) leave as one 16-byte store; scan order is applied by the readers (LaneConst::zsrc)
                 uint4 o;
-                o.x = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x05040100u);
-                o.y = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x05040100u);
-                o.z = __builtin_amdgcn_perm((uint32_t)d[5], (uint32_t)d[4], 0x05040100u);
-                o.w = __builtin_amdgcn_perm((uint32_t)d[7], (uint32_t)d[6], 0x05040100u);
+                o.x = pack_sh17(d[1], d[0]);
+                o.y = pack_sh17(d[3], d[2]);
+                o.z = pack_sh17(d[5], d[4]);
+                o.w = pack_sh17(d[7], d[6]);
                 *(uint4*)&tileZ[lane * 8] = o;
             }
             wave_sync();     // tileZ holds the macroblock's coefficients: block b, column c, row r at [b * 64 + c * 8 + r]
@@ -1180,10 +1244,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_PILOT_N] = 4;
                 L.scalars[S_PILOT_SCALE0 + 0] = 1;
                 L.scalars[S_PILOT_SCALE0 + 1] = 2;
-                L.scalars[S_PILOT_SCALE0 + 2] = 4;
-                L.scalars[S_PILOT_SCALE0 + 3] = 8;
+                L.scalars[S_PILOT_SCALE0 + 2] = in_loop(4);
+                L.scalars[S_PILOT_SCALE0 + 3] = in_loop(8);
             }
-            L.scalars[S_PILOT_LO] = 0;       // largest scale estimated not to fit
+            L.scalars[S_PILOT_LO] = in_loop(0);       // largest scale estimated not to fit
             L.scalars[S_PILOT_HI] = in_loop(64);      // smallest scale estimated to fit
         }
         for (;;) {
@@ -1245,9 +1309,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         //      described by two scalars
         MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
         if (tid == 0) {
+            L.scalars[S_NEXT_DRAW] = (int)next_draw;
             MdecSearch st;
             mdec_search_init(st);
             st.best = in_loop(st.best);
+            {       // (the zeros too: as loop-invariant constants they took two registers for the whole kernel -- and a scratch slot)
+                const int z = in_loop(0);
+                st.lo = z; st.staged = z; st.pad = z;
+                st.fail = (uint64_t)(uint32_t)z | ((uint64_t)(uint32_t)in_loop(0) << 32);
+                st.fs[0] = st.fs[1] = st.fb[0] = st.fb[1] = z;
+                st.gs[0] = st.gs[1] = st.gb[0] = st.gb[1] = z;
+            }
             MdecPass np;
             if (limit_bits < fixed_bits || bad_budget) {
                 np.done = 1; np.count_scale = 0; np.emit_scale = 0;
@@ -1298,7 +1370,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
             const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
             const uint32_t low_off = thr_low - 1u, low_span = 2u * thr_low - 1u, emit_off = thr_emit - 1u, emit_span = 2u * thr_emit - 1u;
-            const uint32_t lane_tag = (uint32_t)lane << 17;
+            auto lane_tag_now = [&]() -> uint32_t { return (uint32_t)in_loop(lane) << 17; };
             // per-wavefront totals -> LDS (also used by the checkpoint: flushing resets the partial sums)
             auto flush = [&]() {
                 if (count_scale) {
@@ -1380,7 +1452,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     uint32_t b_lo, b_hi;
                     mb_bytes(ts, b_lo, b_hi);
                     fetch_behind(nfx, nfy, b_lo, b_hi);
-                    if (valid) dct_mb(ts, b_lo, b_hi);
+                    if (kStopAfter == 1) { asm volatile("" :: "v"(b_lo), "v"(b_hi)); }
+                    else if (valid) dct_mb(ts, b_lo, b_hi);
                 }
                 cur_t = nxt_t;
                 cur_o = nxt_o;
@@ -1388,7 +1461,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 nxt_o = nxt_t < n_tickets ? order[nxt_t] : kNoMb;
                 if (!valid) continue;
                 mb_done++;
+                if (kStopAfter == 1 || kStopAfter == 2) continue;
 
+                const int cs = count_scale;
                 int ci[6];       // this lane's coefficient (scan position = lane) of each block; lane 0 (the DC slot) holds 0
 #pragma unroll
                 for (int b = 0; b < 6; b++) ci[b] = (int)tileZ[b * kZStride + lc.zsrc];
@@ -1412,6 +1487,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      emit scale and counted in place (count_mb): walking a long list costs more than it saves.
                     auto build_list = [&](uint32_t off, uint32_t span) -> int {
                         int c = 0;                             // wave-uniform
+                        const uint32_t lane_tag = lane_tag_now();
 #pragma unroll
                         for (int b = 0; b < 6; b++) {
                             const bool keep = (uint32_t)ci[b] + off >= span;
@@ -1424,18 +1500,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     // (built straight away; only after a dense macroblock the next one is sized up first -- busy content comes in runs)
                     bool dense = false, list_low = false;      // list_low: the list holds the count scale's codes
                     int count = 0;
-                    if (count_scale && dense_prev) {
+                    if (cs && dense_prev) {
                         int n_low = 0;
 #pragma unroll
                         for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot((uint32_t)ci[b] + low_off >= low_span));
                         dense = n_low > 122;
                     }
                     if (!dense) {
-                        count = count_scale ? build_list(low_off, low_span) : build_list(emit_off, emit_span);
-                        list_low = count_scale != 0;
-                        dense = count_scale && count > 128;
+                        count = cs ? build_list(low_off, low_span) : build_list(emit_off, emit_span);
+                        list_low = cs != 0;
+                        dense = cs && count > 128;
                     }
                     dense_prev = dense;
+                    if (kStopAfter == 3) { asm volatile("" :: "s"(count)); wave_sync(); continue; }
                     if (dense) {
                         float cff[6];
 #pragma unroll
@@ -1457,10 +1534,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      as two extra leading bits of the NEXT block's DC code; the macroblock's last one is appended by
                     //      stage_alloc().
                     int kcarry_a = 0, kcarry_b = 0, bcarry = 0;
-                    auto chunk = [&](int base, bool low, bool do_count, int& len, uint32_t& code, int& deficit, int& cnt16, int& ncodes) {
+                    // (low / do_count / single are compile-time: as run-time flags they cost a dozen scalar instructions and several
+                    //  branches per chunk -- and scalar instructions weigh as much as vector ones here)
+                    auto chunk = [&](auto low_tag, auto count_tag, auto single_tag, int base, int& len, uint32_t& code, int& deficit, int& cnt16, int& ncodes) {
+                        constexpr bool low = decltype(low_tag)::value, do_count = decltype(count_tag)::value, single = decltype(single_tag)::value;
                         const int i = base + lane;
                         const bool live = i < count;
-                        const uint32_t e = live ? clist[i] : (63u << 17);      // dead lanes: |n| = 0 at scan position 63
+                        uint32_t e = clist[i];                                  // (always inside the wavefront's tiles: i < 384)
+                        e = live ? e : (63u << 17);                             // dead lanes: |n| = 0 at scan position 63
                         const int k = (int)((e >> 17) & 63u);
                         const bool neg = (e & 0x10000u) != 0;
                         const bool is_dc = k == 0;
@@ -1482,21 +1563,21 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                                 const int qa = quant_mag(magf, ck);
                                 cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
                             }
-                            kcarry_a = __builtin_amdgcn_readlane(k, 63);
+                            if (!single) kcarry_a = __builtin_amdgcn_readlane(k, 63);
                         }
                         int q = quant_mag(magf, ek);                           // <= 2048
                         if (low) {
                             // previous surviving entry
                             const uint64_t sm = wave::ballot(q != 0) | dcm;   // (dead lanes: |n| = 0 at position 63)
                             ncodes = (int)__builtin_popcountll(sm);
-                            const uint64_t below = sm & lc.below;
+                            const uint64_t below = sm & ((1ull << in_loop(lane)) - 1ull);
                             const int ps = 63 - __clzll((long long)below);         // -1 when there is none in this chunk
                             const int kp = __builtin_amdgcn_ds_bpermute(ps << 2, k);
                             kprev = below ? kp : kcarry_b;
-                            if (sm) kcarry_b = __builtin_amdgcn_readlane(k, 63 - __builtin_clzll(sm));
+                            if (!single && sm) kcarry_b = __builtin_amdgcn_readlane(k, 63 - __builtin_clzll(sm));
                         } else {
                             kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
-                            kcarry_b = __builtin_amdgcn_readlane(k, 63);
+                            if (!single) kcarry_b = __builtin_amdgcn_readlane(k, 63);
                             ncodes = count - base < 64 ? count - base : 64;      // a list at the emit scale: every entry is a code
                         }
                         const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
@@ -1527,9 +1608,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                                     len += 2;
                                 }
                             }
-                            bcarry += (int)__builtin_popcountll(dcmask);
+                            if (!single) bcarry += (int)__builtin_popcountll(dcmask);
                         }
                     };
+                    constexpr std::true_type yes{};
+                    constexpr std::false_type no{};
                     // staging for a macroblock of `total` bits (+ the last block's end-of-block code): returns its bit position
                     bool have_room = true;
                     auto stage_alloc = [&](uint32_t total) -> uint32_t {
@@ -1559,7 +1642,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         for (int base = 0; base < count; base += 64) {
                             const int i = base + lane;
                             const bool live = i < count;
-                            const uint32_t e = live ? clist[i] : (63u << 17);
+                            uint32_t e = clist[i];
+                            e = live ? e : (63u << 17);
                             const int k = (int)((e >> 17) & 63u);
                             const bool is_dc = k == 0;
                             const bool is_ac = live && !is_dc;
@@ -1586,7 +1670,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (count <= 64) {
                         int len, deficit, cnt16, nc;
                         uint32_t code;
-                        chunk(0, low, low, len, code, deficit, cnt16, nc);
+                        if (low) chunk(yes, yes, yes, 0, len, code, deficit, cnt16, nc);
+                        else chunk(no, no, yes, 0, len, code, deficit, cnt16, nc);
                         const int incl = wave::inclusive_scan_add(len);
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
                         if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
@@ -1599,9 +1684,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         for (int base = 0; base < count; base += 64) {
                             int len, deficit, cnt16, nc;
                             uint32_t code;
-                            chunk(base, low, low, len, code, deficit, cnt16, nc);
+                            chunk(no, no, no, base, len, code, deficit, cnt16, nc);      // (a list of several chunks is at the emit scale: see the recompaction above)
                             lsum += len;
-                            acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
                         }
                         uint32_t pos = stage_alloc((uint32_t)wave::reduce_add(lsum));
                         kcarry_a = 0;
@@ -1610,7 +1694,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         for (int base = 0; base < count; base += 64) {
                             int len, deficit, cnt16, nc;
                             uint32_t code;
-                            chunk(base, low, false, len, code, deficit, cnt16, nc);
+                            chunk(no, no, no, base, len, code, deficit, cnt16, nc);
                             const int incl = wave::inclusive_scan_add(len);
                             if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
@@ -1646,10 +1730,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // launch used to last as long as the group that drew two such frames (noise +-8: 250 us against a median group's
                 // 170); retries are now drawn like tickets.  The result of a frame never depends on who encodes it or from which guess.
                 auto hand_on = [&](const MdecPass& np) -> bool {
-                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || next_draw >= fresh_draws) return false;
+                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || (unsigned)L.scalars[S_NEXT_DRAW] >= fresh_draws) return false;
                     const unsigned slot = (unsigned)(atomicAdd(queue_state(job), 1ull << kQueueReservedShift) >> kQueueReservedShift) & kQueueMask;
-                    if (atomicExch(&job.retry[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
-                        atomicExch(&job.retry[slot], kRetryEmpty);      // the group this slot belonged to has left: the frame stays here
+                    if (atomicExch(&retry_slots(job)[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
+                        atomicExch(&retry_slots(job)[slot], (unsigned)in_loop((int)kRetryEmpty));      // the group this slot belonged to has left: the frame stays here
                         return false;
                     }
                     L.scalars[S_DEFER] = 1;
@@ -1702,6 +1786,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 }
                 }
             }
+            if (kStopAfter && tid == 0) L.scalars[S_DONE] = 1;
             group_sync(4);
         }
         n_done++;
@@ -1738,7 +1823,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         {
             outp = job.batch[0].out + (size_t)fl * job.out_stride;
             b_results = job.batch[0].results + fl;
-            if (job.n_batches > 1) {
+            if (PSX_BATCHES_MANY()) {
                 BatchPtr bt = batch_table();
                 outp = bt[bi].out + (size_t)fl * job.out_stride;
                 b_results = bt[bi].results + fl;
@@ -1914,7 +1999,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 const unsigned long long w = atomicAdd(queue_state(job), 0ull);
                 unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;
                 if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
-                for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) job.retry[i] = kRetryEmpty;
+                for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) retry_slots(job)[i] = kRetryEmpty;
             }
             *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
             __threadfence();
@@ -1952,9 +2037,10 @@ __global__ __launch_bounds__(64) void mdec_fdct_probe_kernel(const int16_t* in, 
     __syncthreads();
     if (live) {
         const uint4 q = *(const uint4*)&tile[blk * kTileStride + r8 * 8];
-        fdct8_pk<true>(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+        fdct8_col_acc(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+        const uint32_t o[4] = {pack_sh17(d[1], d[0]), pack_sh17(d[3], d[2]), pack_sh17(d[5], d[4]), pack_sh17(d[7], d[6])};      // as the frame kernel packs them
 #pragma unroll
-        for (int v = 0; v < 8; v++) out[(size_t)b * 64 + v * 8 + r8] = (int16_t)d[v];
+        for (int v = 0; v < 8; v++) out[(size_t)b * 64 + v * 8 + r8] = (int16_t)(o[v >> 1] >> (16 * (v & 1)));
     }
 }
 

@@ -215,3 +215,23 @@ def test_dct_linear_forms():
         O.lib().orc_fdct_islow8(O.ptr(want[i], O.i16p))
     assert np.array_equal(cols.reshape(-1, 64), want.astype(np.int64))
     assert np.array_equal(cols[:, 0, 0], (blocks - 128).sum(axis=(1, 2)))   # DC == sum of the level-shifted samples (v3 pre-pass)
+
+
+def test_integer_identities_of_the_kernel():
+    """Arithmetic rewrites the frame kernel relies on (psxavenc_amd/csrc/mdec_kernels.hip), checked over their whole ranges:
+    * quant_dc: sgn(c) * ((|c| + 8) >> 4) == (c + 8 + (c >> 31)) >> 4  (the DC quantiser DIVIDE_ROUNDED(c, 16), mdec.c:438,447);
+    * column pass: out = (acc + 2^16) >> 17 taken as ((acc + 2^16) >> 16) >> 1 from the accumulator's HIGH half (pack_sh17);
+    * column pass outputs 0 / 4: (sum + 8) >> 4 == (8192 * sum + 2^16) >> 17, and 8192 * sum stays inside int32."""
+    c = np.arange(-140000, 140000, dtype=np.int64)
+    a = np.abs(c)
+    q = (a + 8) >> 4
+    assert np.array_equal(np.where(c < 0, -q, q), (c + 8 + (c >> 63)) >> 4)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.integers(-2**31, 2**31 - 2**16, 2_000_000, dtype=np.int64), np.arange(-70000, 70000, dtype=np.int64),
+                        np.array([-2**31, 2**31 - 2**16 - 1], np.int64)])
+    acc = x + 65536
+    hi = (acc.astype(np.int32).view(np.int32) >> 16).astype(np.int16)          # the high half, as the byte permute takes it
+    assert np.array_equal((acc >> 17).astype(np.int64), (hi.astype(np.int64) >> 1))
+    s = np.arange(-4 * 32640, 4 * 32640 + 1, dtype=np.int64)                    # |sum| <= 4 * (32768 - 128)
+    assert np.abs(8192 * s + 65536).max() < 2**31
+    assert np.array_equal((s + 8) >> 4, (8192 * s + 65536) >> 17)
