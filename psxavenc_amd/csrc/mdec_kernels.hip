@@ -952,6 +952,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 const int luma_items = (H >> 3) * gpr, total_items = luma_items + (H >> 4) * gpr;
                 const int r = lane & 7, cl = lane >> 3;
                 auto item_addr = [&](int item, bool& chroma, int& R, int& c, bool& ok) -> const uint8_t* {
+#ifdef PSX_EXP_DC_REVERSE      // experiment: walk the frame bottom to top, luma and chroma interleaved, so that what the main pass reads first was read last
+                    if (item < total_items) {
+                        const int t = total_items - 1 - item, k = t / (3 * gpr), r = t - k * 3 * gpr;
+                        item = r < 2 * gpr ? 2 * k * gpr + r : luma_items + k * gpr + (r - 2 * gpr);
+                    }
+#endif
                     chroma = item >= luma_items;
                     const int it2 = chroma ? item - luma_items : item;
                     R = it2 / gpr;
@@ -1369,7 +1375,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // (|n| >= t  <=>  (unsigned)(n + t - 1) >= 2 t - 1: one add and one compare, no absolute value)
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
             const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
-            const uint32_t low_off = thr_low - 1u, low_span = 2u * thr_low - 1u, emit_off = thr_emit - 1u, emit_span = 2u * thr_emit - 1u;
+            // (lane 0 -- scan position 0, the block's DC slot -- is always kept: its span is 0, and x + off >= 0 always holds)
+            const uint32_t low_off = thr_low - 1u, low_span = lane == 0 ? 0u : 2u * thr_low - 1u;
+            const uint32_t emit_off = thr_emit - 1u, emit_span = lane == 0 ? 0u : 2u * thr_emit - 1u;
             auto lane_tag_now = [&]() -> uint32_t { return (uint32_t)in_loop(lane) << 17; };
             // per-wavefront totals -> LDS (also used by the checkpoint: flushing resets the partial sums)
             auto flush = [&]() {
@@ -1486,13 +1494,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      A macroblock that is dense at the count scale (a list of more than two chunks) is listed again at the
                     //      emit scale and counted in place (count_mb): walking a long list costs more than it saves.
                     auto build_list = [&](uint32_t off, uint32_t span) -> int {
+                        // (everything but the store itself is computed by all lanes: the masked region is one instruction, and the
+                        //  mask is the compare's own result -- lane 0 keeps by construction, see low_span)
                         int c = 0;                             // wave-uniform
                         const uint32_t lane_tag = lane_tag_now();
 #pragma unroll
                         for (int b = 0; b < 6; b++) {
                             const bool keep = (uint32_t)ci[b] + off >= span;
-                            const uint64_t mk = wave::ballot(keep) | 1ull;
-                            if (keep || lane == 0) clist[c + wave::popc_below(mk)] = ((uint32_t)ci[b] & 0x1FFFFu) | lane_tag;
+                            const uint64_t mk = wave::ballot(keep);
+                            uint32_t* const slot = &clist[c + wave::popc_below(mk)];
+                            const uint32_t entry = ((uint32_t)ci[b] & 0x1FFFFu) | lane_tag;
+                            if (keep) *slot = entry;
                             c += (int)__builtin_popcountll(mk);
                         }
                         return c;
@@ -1504,7 +1516,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         int n_low = 0;
 #pragma unroll
                         for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot((uint32_t)ci[b] + low_off >= low_span));
-                        dense = n_low > 122;
+                        dense = n_low > 128;      // (the six DC slots included)
                     }
                     if (!dense) {
                         count = cs ? build_list(low_off, low_span) : build_list(emit_off, emit_span);
@@ -1550,6 +1562,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
                         cnt16 = 0;
                         int kprev;
+                        bool is_last;
                         // the quantiser constants belong to the entry's scan position k, i.e. they sit in lane k's registers
                         QuantK ek;
                         ek.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, ke.inv)));
@@ -1575,7 +1588,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             const int kp = __builtin_amdgcn_ds_bpermute(ps << 2, k);
                             kprev = below ? kp : kcarry_b;
                             if (!single && sm) kcarry_b = __builtin_amdgcn_readlane(k, 63 - __builtin_clzll(sm));
+                            is_last = lane == 63 - __builtin_clzll(sm);       // (a list at the count scale is one chunk; DC slots survive: sm != 0)
                         } else {
+                            is_last = i == count - 1;
                             kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
                             if (!single) kcarry_b = __builtin_amdgcn_readlane(k, 63);
                             ncodes = count - base < 64 ? count - base : 64;      // a list at the emit scale: every entry is a code
@@ -1610,27 +1625,37 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             }
                             if (!single) bcarry += (int)__builtin_popcountll(dcmask);
                         }
+                        // the macroblock's LAST code carries the last block's end-of-block code behind it, the way every other
+                        // end-of-block code rides in front of the next block's DC code: no separate two-bit write by one lane
+                        {
+                            const int add = is_last ? 2 : 0;
+                            code = (code << add) | (uint32_t)add;
+                            len += add;
+                        }
                     };
                     constexpr std::true_type yes{};
                     constexpr std::false_type no{};
-                    // staging for a macroblock of `total` bits (+ the last block's end-of-block code): returns its bit position
+                    // staging for a macroblock of `mb_bits` bits (all six end-of-block codes included): returns its bit position
                     bool have_room = true;
-                    auto stage_alloc = [&](uint32_t total) -> uint32_t {
-                        const uint32_t mb_bits = total + 2u;
+                    auto stage_alloc = [&](uint32_t mb_bits) -> uint32_t {
                         const int ndw = (int)((mb_bits + 31u) >> 5);
                         int off = 0;
                         if (lane == 0) off = atomicAdd(&L.scalars[S_STG_NEXT], ndw);
                         off = __builtin_amdgcn_readfirstlane(off);
                         have_room = off + ndw <= job.stg_words;
                         if (lane == 0) {
-                            if (!have_room) L.scalars[S_OVERFLOW] = 1;
                             L.rec[mbe] = ((uint32_t)off & 0xFFFFu) | (mb_bits << 16);
-                            if (have_room) put_bits(L.stg, (uint32_t)off * 32u + total, 2, 2u);
+                            if (!have_room) L.scalars[S_OVERFLOW] = 1;
                         }
                         emit_bits += (int)mb_bits;
                         emit_sq += (mb_bits >> 2) * (mb_bits >> 2);
                         emit_s1 += mb_bits >> 2;
                         return (uint32_t)off * 32u;
+                    };
+                    // (lanes without a code stay out: an OR of nothing is still an LDS atomic on a neighbour's dword -- tried, +57 % bank
+                    //  conflict cycles and 12 % slower on 640x480, whose chunks have more idle lanes)
+                    auto put_codes = [&](uint32_t pos, int len, uint32_t code) {
+                        if (have_room && len) put_bits(L.stg, pos, len, code);
                     };
                     bool low = list_low;
                     if (low && count > 64) {
@@ -1674,7 +1699,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         else chunk(no, no, yes, 0, len, code, deficit, cnt16, nc);
                         const int incl = wave::inclusive_scan_add(len);
                         const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
-                        if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
+                        put_codes(pos + (uint32_t)(incl - len), len, code);
                         acc_edef += deficit;
                         acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
                         n_codes += nc;
@@ -1696,7 +1721,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             uint32_t code;
                             chunk(no, no, no, base, len, code, deficit, cnt16, nc);
                             const int incl = wave::inclusive_scan_add(len);
-                            if (have_room && len) put_bits(L.stg, pos + (uint32_t)(incl - len), len, code);
+                            put_codes(pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                             acc_edef += deficit;
                             n_codes += nc;
