@@ -467,6 +467,7 @@ def _main():
                 for e in encs:          # (the children get the GPU to themselves)
                     e.close()
                 encs = []
+                secondary["per_call_drop_in"] = _secondary_per_call()
                 secondary.update(_secondary_configs(args))
 
     version = _lib.lib().psxhip_version().decode()
@@ -706,6 +707,18 @@ def _secondary_device_list(args, torch, w, h, budget, d_batches):
         m.close()
         return out
     except Exception as e:      # secondary figures never fail the bench line
+        return {"error": repr(e)}
+
+
+def _secondary_per_call():
+    """The reference's own call pattern on the drop-in surface -- psx_audio_spu_encode per 28 samples (filefmt.c:243),
+    psx_audio_xa_encode per sector (:184), encode_frame_bs per frame (:643) -- timed by a plain-C harness (examples/percall_bench.c)."""
+    import subprocess
+    try:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "examples"), "percall_bench"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([os.path.join(ROOT, "examples", "percall_bench"), "2000", "300", "300"], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
         return {"error": repr(e)}
 
 

@@ -478,3 +478,18 @@ def test_str_mux_randomised_settings_vs_reference_loop():
         done += 1
     assert done >= 25
     mux.close()
+
+
+def test_per_call_harness_builds_and_runs():
+    """examples/percall_bench.c: plain C over the three drop-in calls at the reference's own granularity (one launch per call)"""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "examples")], check=True)
+    r = subprocess.run([os.path.join(root, "examples", "percall_bench"), "300", "40", "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("psx_audio_spu_encode_28_samples", "psx_audio_xa_encode_sector", "encode_frame_bs_320x240_v2"):
+        assert d[k]["us_per_call_median"] > 0
+    assert d["encode_frame_bs_320x240_v2"]["quant_scale_sum"] > 0
