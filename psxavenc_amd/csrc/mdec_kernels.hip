@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <stdlib.h>
 #include <string.h>
 
 #include "bs_vlc_lut.h"
@@ -106,7 +107,7 @@ struct FrameJob {
     int stg_words;           // LDS dwords of the macroblock staging area
     int trips;               // iterations of a pass: ceil(nmb / wavefronts per group)
     int it_step;             // iteration visiting stride (coprime with trips), see psxhip_mdec_pass_order()
-    const uint32_t* order;   // [trips * wavefronts per group] macroblock visited by pass ticket t: fx | fy << 8, or kNoMb
+    const uint32_t* order;   // [2 * trips * wavefronts per group] per pass ticket t: what the loop needs of its macroblock (psxhip_mdec_pass_table)
     unsigned int* ticket;    // [128] of this launch's LANE: [1] workgroups finished (self-resetting), [3] frames lost by the retry queue's watchdog (never reset; psxhip_mdec_watchdog), [64..65] frame tickets + the retry queue's state, one 64-bit word, [96] groups started (self-resetting)
     unsigned int* hint;      // one word shared by the context's lanes: answer | budget << 8 of the last frame (by index) of the launch that wrote it last -- a hint that survives launches
     unsigned int* retry;     // [retry_cap] retry queue: frame | scale to start from << 24, kRetryEmpty when vacant (NULL: frames are never handed on)
@@ -1128,15 +1129,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         float cf[6];            // this lane's coefficient of each block of the current macroblock, as float; lane 0 holds 0
         uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);
 
-        auto fetch = [&](int fx, int fy) {
+        auto fetch_at = [&](uint32_t row, uint32_t col) {       // row = fy * 8 W, col = fx * 16
             // 32-bit offsets from the (wave-uniform) frame pointer; the macroblock row's offset is scalar arithmetic, a lane
             // only shifts it (a macroblock row is 8 W bytes of chroma, 16 W of luma)
             const uint4 tp = L.tab_pix[lane];
-            const uint32_t row = (uint32_t)fy * (uint32_t)(8 * W), col = (uint32_t)fx * 16u;
             const uint32_t o_lo = tp.x + (row << tp.z) + col, o_hi = o_lo + tp.y;
             plo = *(const uint2*)(frame + o_lo);
             phi = *(const uint2*)(frame + o_hi);
         };
+        auto fetch = [&](int fx, int fy) { fetch_at((uint32_t)fy * (uint32_t)(8 * W), (uint32_t)fx * 16u); };
         // the lane's 8 pixels as bytes (b_lo: p0..p3, b_hi: p4..p7) from what fetch() left in (plo, phi)
         auto mb_bytes = [&](const uint4& ts, uint32_t& b_lo, uint32_t& b_hi) {
             b_lo = __builtin_amdgcn_perm(plo.y, plo.x, ts.x);
@@ -1147,10 +1148,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // registers the permutes have just read.  (Issued under `if (there is a next one)`, and hoisted above the permutes by
         // the scheduler, the loads needed a second set of four registers and 8 v_mov per macroblock to shuttle between the sets
         // -- 3 % of the loop's VALU instructions.)
-        auto fetch_behind = [&](int fx, int fy, uint32_t& b_lo, uint32_t& b_hi) {
+        auto fetch_behind = [&](uint32_t row, uint32_t col, uint32_t& b_lo, uint32_t& b_hi) {      // row = fy * 8 W, col = fx * 16 (what the pass table holds)
             asm volatile("" : "+v"(b_lo), "+v"(b_hi));
             const uint4 tp = L.tab_pix[lane];
-            const uint32_t row = (uint32_t)fy * (uint32_t)(8 * W), col = (uint32_t)fx * 16u;
             uint32_t o_lo = tp.x + (row << tp.z) + col;
             asm volatile("" : "+v"(o_lo) : "v"(b_lo), "v"(b_hi));      // the address is "made from" the bytes: the loads stay behind the permutes
             const uint32_t o_hi = o_lo + tp.y;
@@ -1356,13 +1356,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // (psxhip_mdec_pass_order) spreads every run of tickets evenly over the frame.  A wavefront's first two tickets are
             // its own; from then on it draws the ticket after next while it works, so that neither the counter's round trip nor
             // the order look-up (a scalar load) nor the pixel fetch of the next macroblock is waited for.
+            // A table entry is what the loop needs of its macroblock, ready made (psxhip_mdec_pass_table): x = fy * 8 W (the
+            // macroblock row's byte offset in the chroma plane; luma lanes shift it) | valid << 31, y = fx * 16 | encode-order
+            // index << 16.  An entry without a macroblock is all zero: its fetch reads macroblock (0, 0), no select needed.
             typedef const uint32_t __attribute__((address_space(4))) * OrderPtr;
-            const OrderPtr order = (OrderPtr)(uintptr_t)job.order;
+            const OrderPtr order_w = (OrderPtr)(uintptr_t)job.order;
+            auto order_at = [&](int t) -> uint2 { return make_uint2(order_w[2 * t], order_w[2 * t + 1]); };
             const int n_tickets = job.trips * kWavesPerGroup;
             int cur_t = wid, nxt_t = wid + kWavesPerGroup;
-            uint32_t cur_o = order[cur_t];
-            uint32_t nxt_o = nxt_t < n_tickets ? order[nxt_t] : kNoMb;
-            if (cur_o != kNoMb) fetch((int)(cur_o & 0xFFu), (int)(cur_o >> 8));
+            uint2 cur_o = order_at(cur_t);
+            uint2 nxt_o = nxt_t < n_tickets ? order_at(nxt_t) : make_uint2(0u, 0u);
+            fetch_at(cur_o.x & 0x7FFFFFFFu, cur_o.y & 0xFFFFu);
             const QuantK kc = make_quant(lc.quant, count_scale ? count_scale : 1);
             const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
             int acc_cnt = 0;             // per lane: bits | deficit << 16 over this wavefront's macroblocks (count scale)
@@ -1447,26 +1451,27 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                 }
                 if (WAVES == kWavesSmall) {
-                    if ((prio_bits >> (it & 7)) & 1u) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
+                    // (s_setprio takes an immediate, so this IS a branch; written out, because the compiler's own if / else around
+                    //  the two builtins came to eight scalar instructions and two branches per macroblock)
+                    const unsigned pbit = prio_bits >> (it & 7);
+                    asm volatile("s_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\ts_setprio 1\n2:" : : "s"(pbit) : "scc");
                 }
                 int drawn = 0;
                 if (lane == 0) drawn = atomicAdd(&L.scalars[S_MB_NEXT], 1);
-                const bool valid = cur_o != kNoMb, nxt_valid = nxt_o != kNoMb;
-                const int nfx = nxt_valid ? (int)(nxt_o & 0xFFu) : 0, nfy = nxt_valid ? (int)(nxt_o >> 8) : 0;
-                const int mbe = (int)(cur_o & 0xFFu) * ny + (int)(cur_o >> 8);
+                const bool valid = (int)cur_o.x < 0;
+                const int mbe = (int)(cur_o.y >> 16);
                 {
                     const uint4 ts = L.tab_sel[lane];
                     uint32_t b_lo, b_hi;
                     mb_bytes(ts, b_lo, b_hi);
-                    fetch_behind(nfx, nfy, b_lo, b_hi);
+                    fetch_behind(nxt_o.x & 0x7FFFFFFFu, nxt_o.y & 0xFFFFu, b_lo, b_hi);
                     if (kStopAfter == 1) { asm volatile("" :: "v"(b_lo), "v"(b_hi)); }
                     else if (valid) dct_mb(ts, b_lo, b_hi);
                 }
                 cur_t = nxt_t;
                 cur_o = nxt_o;
                 nxt_t = __builtin_amdgcn_readfirstlane(drawn);
-                nxt_o = nxt_t < n_tickets ? order[nxt_t] : kNoMb;
+                nxt_o = nxt_t < n_tickets ? order_at(nxt_t) : make_uint2(0u, 0u);
                 if (!valid) continue;
                 mb_done++;
                 if (kStopAfter == 1 || kStopAfter == 2) continue;
@@ -2150,6 +2155,25 @@ extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t
         const int m = w + ((r * step) % trips) * waves;
         out[t] = m < nmb ? (uint32_t)(m % nx) | (uint32_t)(m / nx) << 8 : kNoMb;
     }
+    return n;
+}
+
+// ... and the same order as the kernel reads it: per ticket {fy * 8 W | valid << 31, fx * 16 | encode-order index << 16} (an entry
+// without a macroblock is all zero).  Returns the number of tickets.
+extern "C" int psxhip_mdec_pass_table(int width, int height, int large, uint32_t* out /* [2 * n] */, int cap) {
+    const int n = psxhip_mdec_pass_order(width, height, large, nullptr, 0);
+    if (!out) return n;
+    uint32_t* o = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    if (!o) return -1;
+    (void)psxhip_mdec_pass_order(width, height, large, o, n);
+    const int ny = height / 16;
+    for (int t = 0; t < n && t < cap; t++) {
+        if (o[t] == kNoMb) { out[2 * t] = 0u; out[2 * t + 1] = 0u; continue; }
+        const uint32_t fx = o[t] & 0xFFu, fy = o[t] >> 8;
+        out[2 * t] = (fy * 8u * (uint32_t)width) | 0x80000000u;
+        out[2 * t + 1] = (fx * 16u) | ((fx * (uint32_t)ny + fy) << 16);
+    }
+    free(o);
     return n;
 }
 

@@ -36,7 +36,7 @@ typedef struct {
 	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
 	unsigned prio_pattern;          /* see FrameJob */
 	int ck_margin;                  /* checkpoint margin in thousandths of the projection's standard error (0 = default) */
-	const uint32_t *d_order;        /* psxhip_mdec_pass_order() for this geometry, in device memory */
+	const uint32_t *d_order;        /* psxhip_mdec_pass_table() for this geometry, in device memory */
 } psxhip_mdec_launch_t;
 
 size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int stg_words, int large);
@@ -44,6 +44,7 @@ int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int cap);
+int psxhip_mdec_pass_table(int width, int height, int large, uint32_t *out /* [2 * n] */, int cap);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
 hipError_t psxhip_mdec_stage_in_launch(const void *src_mapped, void *d_dst, size_t bytes, void *stream);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
