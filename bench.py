@@ -414,24 +414,32 @@ def _main():
     achieved_local = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
     if ns > 1:      # launches overlap: a launch's own duration says little, the aggregate rate is what the GPU sustains
         achieved_local = alg_bytes * args.steps * lps / elapsed_local / 1e9
-    in_order = None
+    overlapped = None
     if lanes > 1:
-        # the same launches in strict stream order (one lane), right after the timed region: a launch's own duration, the figure
-        # rocprofv3's per-kernel average of an in-order run agrees with
+        # With two launch lanes consecutive launches overlap, and a step's event time / its launches is a launch's SHARE of the
+        # GPU's time, not its duration.  The roofline block describes the KERNEL: its duration is measured right here, live, with
+        # HIP events around the same launches in strict stream order (one lane: every launch waits for the one before) -- the
+        # figure rocprofv3's per-kernel average of `bench.py --lanes 1` agrees with (profiles/).  `value` stays the timed region's.
+        overlapped = {"launch_lanes": lanes, "ms_per_launch_share": kstat["mean"], "share_stats": kstat,
+                      "achieved": round(alg_bytes / (kstat["mean"] * 1e-3) / 1e9, 3), "frac": round(alg_bytes / (kstat["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                      "note": "algorithmic bytes of a launch / (a step's HIP-event time / its launches): what the GPU sustains with the head of launch k+1 "
+                              "filling the tail of launch k; in a kernel trace of this run a kernel's own span is about twice its share"}
         enc.set_lanes(1)
         m = min(lps, 400)
         for k in range(m // 4):
             launch(k)
-        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a_.record(streams[0])
-        for k in range(m):
-            launch(k)
-        b_.record(streams[0])
-        torch.cuda.synchronize()
-        io_ms = a_.elapsed_time(b_) / m
-        in_order = {"lanes": 1, "kernel_ms": round(io_ms, 5), "launches": m, "frames_per_sec": round(n / io_ms * 1e3, 1),
-                    "achieved": round((fsz + budget) * n / (io_ms * 1e-3) / 1e9, 3), "frac": round((fsz + budget) * n / (io_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                    "note": "one launch at a time (psxhip_mdec_set_lanes(1)): every launch waits for the one before, HIP events around %d back-to-back launches" % m}
+        io = []
+        for _blk in range(5):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(streams[0])
+            for k in range(m):
+                launch(k)
+            b_.record(streams[0])
+            torch.cuda.synchronize()
+            io.append(a_.elapsed_time(b_) / m)
+        kstat = _stats(io)
+        kstat["launches"] = 5 * m
+        achieved_local = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
         enc.set_lanes(lanes)
     per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(n * args.steps * lps), kstat["mean"], achieved_local])
     elapsed = max(r[0] for r in per_rank)                   # max over ranks
@@ -478,7 +486,7 @@ def _main():
     issue = None
     if pmc and pmc.get("valu_insts_per_launch") and not getattr(args, "share_gpu", False):      # (ranks sharing one GPU: a rank's kernel time is not the GPU's)
         simds, clock_ghz = 256 * 4, 2.4
-        eff_ms = kstat["mean"] if ns == 1 else elapsed_local * 1e3 / (args.steps * lps)     # overlapped launches: their share of the wall clock (with lanes the per-step event time / launches IS that share)
+        eff_ms = kstat["mean"] if ns == 1 else elapsed_local * 1e3 / (args.steps * lps)     # (several contexts: their launches' share of the wall clock; launch lanes: kstat is the in-order kernel duration)
         slots = simds * clock_ghz * 1e9 / 4.0 * (eff_ms * 1e-3)
         issue = {"valu_insts_per_launch": pmc["valu_insts_per_launch"], "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
                  "lds_insts_per_launch": pmc.get("lds_insts_per_launch"),
@@ -528,12 +536,11 @@ def _main():
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
-                         "launches_timed": args.steps * lps,
-                         "kernel_ms_method": ("one HIP event pair per step of %d back-to-back launches, / %d; stats over steps" % (lps, lps)) if per_step else "one HIP event pair per launch",
-                         "algorithmic_bytes_per_launch": alg_bytes, "issue": issue, "in_order": in_order,
-                         **({"overlap_note": "with two launch lanes consecutive launches overlap: kernel_ms = a step's HIP-event time / its launches = a launch's SHARE "
-                                             "of the GPU's time (what the rate follows from); one launch by itself lasts in_order.kernel_ms, and in a kernel trace "
-                                             "of this run each kernel's own span is longer than its share because it runs beside its neighbour"} if lanes > 1 else {}),
+                         "launches_timed": (kstat.get("launches") if lanes > 1 else args.steps * lps),
+                         "kernel_ms_method": ("strict stream order (one launch lane), measured after the timed region: one HIP event pair per block of %d back-to-back "
+                                              "launches, / %d; stats over 5 blocks" % (min(lps, 400), min(lps, 400))) if lanes > 1 else
+                                             (("one HIP event pair per step of %d back-to-back launches, / %d; stats over steps" % (lps, lps)) if per_step else "one HIP event pair per launch"),
+                         "algorithmic_bytes_per_launch": alg_bytes, "issue": issue, "overlapped": overlapped,
                          **({"note": "launches of %d contexts overlap: achieved = algorithmic bytes of all launches / elapsed; kernel_ms are "
                                      "per-launch durations while sharing the GPU" % ns} if ns > 1 else {})},
             "cpu_baseline": cpu_baseline,

@@ -12,8 +12,10 @@ mkdir -p $out
 # kernel-trace: the bench's own command line (defaults: 20 steps x 400 launches over 4 distinct batches), so that the kernel's
 # average duration here and bench.py's HIP-event mean are measurements of the same thing; PMC passes: a shorter run of the
 # same workload (counter collection serialises the kernels)
-full="python bench.py --no-cpu-baseline --no-secondary $*"
-cmd="python bench.py --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-secondary $*"
+# --lanes 1: every launch waits for the one before, so a kernel's span in the trace IS its duration (bench.py's default overlaps
+# consecutive launches of its one context; its roofline block measures the in-order duration live, which is what this must agree with)
+full="python bench.py --lanes 1 --launches-per-step 400 --no-cpu-baseline --no-secondary $*"
+cmd="python bench.py --lanes 1 --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-secondary $*"
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- $full > $out/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o r -- $cmd > $out/write.log 2>&1
