@@ -302,6 +302,9 @@ def _main():
                     help="sbs: launch lanes of the encoder context (psxhip_mdec_set_lanes): 1 = every launch ordered on the caller's stream behind "
                          "the one before; 2 (the headline's default) = consecutive launches of the ONE context on the ONE caller stream may overlap "
                          "(inputs ordered on the stream, results ordered by the next call or psxhip_mdec_fence)")
+    ap.add_argument("--device-list", default=None,
+                    help="sbs: devices for the secondary C-ABI device-list leg (psxhip_mdec_multi_*), e.g. '0,0' to run it on a one-GPU box; "
+                         "default: all visible devices when there is more than one")
     ap.add_argument("--no-config-secondaries", action="store_true",
                     help="default run only: skip the other BASELINE configs (sbs_v3 share, xacd, strcd) and the RCCL world-size-1 self-test that "
                          "are run as subprocesses after the timed region")
@@ -469,7 +472,7 @@ def _main():
             cpu_baseline = _cpu_baseline_mdec(args.codec, w, h, budget, args.amp, args.seed, args.cpu_seconds)
         if world == 1 and not args.no_secondary and ns == 1:
             secondary = _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first)
-            if torch.cuda.device_count() > 1:
+            if torch.cuda.device_count() > 1 or args.device_list:
                 secondary["c_abi_device_list"] = _secondary_device_list(args, torch, w, h, budget, d_batches)
             if args.config == "sbs_v2" and not args.no_config_secondaries:
                 for e in encs:          # (the children get the GPU to themselves)
@@ -693,7 +696,7 @@ def _secondary_device_list(args, torch, w, h, budget, d_batches):
     try:
         from psxavenc_amd.mdec import MdecEncoder
         from psxavenc_amd.multi import MdecMulti, SCHED_STATIC, SCHED_TICKETS
-        devs = list(range(torch.cuda.device_count()))
+        devs = [int(x) for x in args.device_list.split(",")] if args.device_list else list(range(torch.cuda.device_count()))
         frames = np.concatenate([b.cpu().numpy() for b in d_batches], axis=0)
         n = frames.shape[0]
         one = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=0)

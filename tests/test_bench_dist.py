@@ -72,6 +72,20 @@ def test_forced_group_without_torchrun_sets_up_its_own_rendezvous():
 
 
 @pytest.mark.gpu
+def test_c_abi_device_list_leg_of_the_bench_line():
+    """the leg a single process runs over ALL visible devices of a multi-GPU node (psxhip_mdec_multi_* with one host thread, context
+    and pinned staging pair per device), forced here onto the list 0,0: both schedules byte-equal to device 0 alone"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "1", "--warmup", "1", "--launches-per-step", "8", "--no-cpu-baseline",
+                        "--no-config-secondaries", "--device-list", "0,0"], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode == 0 and line, (r.stdout[-2000:], r.stderr[-2000:])
+    leg = line["secondary"]["c_abi_device_list"]
+    assert "error" not in leg, leg
+    assert leg["devices"] == [0, 0] and leg["static"]["bit_exact_vs_device_0"] and leg["tickets"]["bit_exact_vs_device_0"]
+    assert sum(d["units"] for d in leg["tickets"]["per_device"]) == leg["frames"]
+
+
+@pytest.mark.gpu
 def test_bad_geometry_is_one_json_error_line_on_the_gpu_box():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--width", "328", "--steps", "1", "--warmup", "0", "--no-secondary",
                         "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
