@@ -100,7 +100,8 @@ int psxhip_mdec_encode_batches_device(psxhip_mdec_ctx_t *ctx, const psxhip_mdec_
  *     next encode call on the context or by psxhip_mdec_fence(ctx, S).  A caller that reads launch k's output (or reuses its
  *     input or output buffers) must have called one of the two first -- i.e. it double-buffers, which is what lets the head of
  *     launch k+1 fill the tail of launch k.
- * Bytes never depend on the number of lanes.  lanes: 1 or 2.  Switching waits for the context's outstanding launches. */
+ * Bytes never depend on the number of lanes.  lanes: 1 or 2.  Switching waits for the context's outstanding launches, and so do
+ * the host-buffer entry points of the same context (psxhip_mdec_encode_frames_host*, encode_frame_bs): they use both lanes. */
 int psxhip_mdec_set_lanes(psxhip_mdec_ctx_t *ctx, int lanes);
 /* order `stream` behind every launch of the context issued so far (a no-op with one lane) */
 int psxhip_mdec_fence(psxhip_mdec_ctx_t *ctx, void *stream);

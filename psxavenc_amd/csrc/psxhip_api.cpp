@@ -558,6 +558,10 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
     }
     if (n_frames == 0) return PSXHIP_OK;
     HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
+    // the host path uses both launch lanes on its own streams: launches the caller left outstanding on them (two lanes, no fence
+    // yet) are waited for first -- a lane's launches must be ordered
+    for (int l = 0; l < kLanes; l++)
+        if (c->lane_pending[l]) HIP_TRY(hipStreamSynchronize(c->lane_stream[l]), PSXHIP_EDEVICE);
     const size_t fsz = (size_t)c->width * c->height * 3 / 2;
     int max_size = uniform_max_size;
     if (frame_max_sizes) {

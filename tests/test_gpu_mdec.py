@@ -737,3 +737,36 @@ def test_two_launch_lanes_overlap_launches_of_one_context_same_bytes(torch_cuda)
     torch.cuda.synchronize()
     assert np.array_equal(o.cpu().numpy(), wants[3][0])
     enc.close()
+
+
+@pytest.mark.gpu
+def test_host_path_after_unfenced_lane_launches(torch_cuda):
+    """two lanes, device launches left outstanding (no fence), then the host-buffer entry points of the same context -- the
+    batch and the single-frame call (mdec.c:580): they wait for the lanes themselves; every byte as with one lane"""
+    torch = torch_cuda
+    w, h, budget, n = 320, 240, 8192, 900
+    frames = O.synth_frames(w, h, n, seed=77, amp=4)
+    d_frames = torch.from_numpy(frames).to("cuda:0")
+    one = encoder(0, w, h, budget)
+    want_o, want_r = one.encode_frames_device(d_frames, budget)
+    torch.cuda.synchronize()
+    want_o, want_r = want_o.cpu().numpy(), want_r.cpu().numpy()
+    one.close()
+    enc = encoder(0, w, h, budget)
+    enc.set_lanes(2)
+    for rep in range(4):
+        d1 = enc.encode_frames_device(d_frames, budget)
+        d2 = enc.encode_frames_device(d_frames, budget)
+        if rep & 1:
+            ho, hr = enc.encode_frames_host(frames[:300], budget)
+            assert np.array_equal(hr, want_r[:300]) and np.array_equal(ho, want_o[:300, :budget])
+        else:
+            enc.frame_max_size = budget
+            bs = enc.encode_frame_bs(frames[5])
+            assert np.array_equal(bs, want_o[5, :budget]) and enc.quant_scale == want_r[5, 0]
+        enc.fence()
+        torch.cuda.synchronize()
+        for o, r in (d1, d2):
+            assert np.array_equal(r.cpu().numpy(), want_r) and np.array_equal(o.cpu().numpy(), want_o)
+    assert enc.watchdog() == 0
+    enc.close()
