@@ -116,6 +116,7 @@ struct FrameJob {
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
     int ck_margin;               // quarter-pass checkpoint: how far (thousandths of its standard error) a projection has to be on the wrong side
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
+    uint32_t col_k[16];          // the column pass's sixteen coefficient pairs (col_coeffs()), fetched by ONE scalar load per macroblock
 };
 // the batch table where it lies in the kernel argument segment (FrameJob is the kernel's only argument, `batch` its first member)
 typedef const BatchDesc __attribute__((address_space(4))) * BatchPtr;
@@ -143,7 +144,7 @@ __device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) { return (u
 enum {
     S_DC_BITS = 0,      // v3: sum of the DC code lengths
     S_STG_NEXT,         // staging bump allocator (dwords)
-    S_OVERFLOW,         // staging ran out during this pass
+    S_OVERFLOW,         // (unused)
     S_CNT_F,            // count pass: sum of AC code lengths
     S_CNT_D,            // count pass: sum of refinement deficits
     S_EMIT_BITS,        // emit pass: sum of macroblock stream lengths
@@ -161,8 +162,8 @@ enum {
     S_PILOT_HI,
     S_CK_DONE,          // checkpoint: macroblocks finished so far in this pass
     S_MB_NEXT,          // pass tickets: next macroblock ticket to hand out
-    S_CK_SQ,            // checkpoint: sum over the macroblocks so far of x^2, x = stream bits >> 2 -> spread of the projection
-    S_CK_S1,            // ... and of x
+    S_CK_SQ,            // (unused)
+    S_CK_S1,            // (unused)
     S_CK_WAVES,         // checkpoint: wavefronts whose sums up to the quarter mark are in
     S_ABORT,            // checkpoint verdict: new guess | pass number << 8 (a verdict of an earlier pass is stale, not reset)
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
@@ -295,6 +296,37 @@ __device__ __forceinline__ void fdct8_col_acc(uint32_t P0, uint32_t P1, uint32_t
     a[5] = dot2_k(D0, pk(C5_3, C5_2), dot2_k(D1, pk(C5_1, C5_0), rnd));
     a[3] = dot2_k(D0, pk(C3_3, C3_2), dot2_k(D1, pk(C3_1, C3_0), rnd));
     a[1] = dot2_k(D0, pk(C1_3, C1_2), dot2_k(D1, pk(C1_1, C1_0), rnd));
+}
+// The same with the sixteen coefficient pairs handed in (in col_coeffs() order) -- the frame kernel loads them into scalar
+// registers with one s_load_dwordx16 per macroblock: as literals they were fifteen s_mov per macroblock, as loop invariants
+// sixteen more scalar registers for a kernel that already spills them.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+struct ColCoeffs { uint32_t k[16]; };
+constexpr ColCoeffs col_coeffs() {
+    constexpr int K_0_298 = 2446, K_0_390 = 3196, K_0_541 = 4433, K_0_765 = 6270, K_0_899 = 7373,
+                  K_1_175 = 9633, K_1_501 = 12299, K_1_847 = 15137, K_1_961 = 16069, K_2_053 = 16819,
+                  K_2_562 = 20995, K_3_072 = 25172;
+    constexpr int A = K_0_541 + K_0_765, B = K_0_541, C = K_0_541 - K_1_847;
+    constexpr int C7_0 = K_0_298 - K_0_899 - K_1_961 + K_1_175, C7_1 = K_1_175, C7_2 = K_1_175 - K_1_961, C7_3 = K_1_175 - K_0_899;
+    constexpr int C5_0 = K_1_175, C5_1 = K_2_053 - K_2_562 - K_0_390 + K_1_175, C5_2 = K_1_175 - K_2_562, C5_3 = K_1_175 - K_0_390;
+    constexpr int C3_0 = K_1_175 - K_1_961, C3_1 = K_1_175 - K_2_562, C3_2 = K_3_072 - K_2_562 - K_1_961 + K_1_175, C3_3 = K_1_175;
+    constexpr int C1_0 = K_1_175 - K_0_899, C1_1 = K_1_175 - K_0_390, C1_2 = K_1_175, C1_3 = K_1_501 - K_0_899 - K_0_390 + K_1_175;
+    constexpr int E = 8192;
+    // pairs (inner product with S1 / D1 first, then with S0 / D0), outputs 0, 4, 2, 6, 7, 5, 3, 1 as in fdct8_col_acc()
+    return ColCoeffs{{pk(E, E), pk(E, E), pk(-E, E), pk(E, -E), pk(-B, -A), pk(A, B), pk(-C, -B), pk(B, C),
+                      pk(C7_1, C7_0), pk(C7_3, C7_2), pk(C5_1, C5_0), pk(C5_3, C5_2), pk(C3_1, C3_0), pk(C3_3, C3_2), pk(C1_1, C1_0), pk(C1_3, C1_2)}};
+}
+__device__ __forceinline__ void fdct8_col_acc_k(uint32_t P0, uint32_t P1, uint32_t R0, uint32_t R1, const u32x16& k, int (&a)[8]) {
+    const uint32_t S0 = pk_add(P0, R0), S1 = pk_add(P1, R1), D0 = pk_sub(P0, R0), D1 = pk_sub(P1, R1);
+    const int rnd = 1 << 16;
+    a[0] = dot2_k(S0, k[1], dot2_k(S1, k[0], rnd));
+    a[4] = dot2_k(S0, k[3], dot2_k(S1, k[2], rnd));
+    a[2] = dot2_k(S0, k[5], dot2_k(S1, k[4], rnd));
+    a[6] = dot2_k(S0, k[7], dot2_k(S1, k[6], rnd));
+    a[7] = dot2_k(D0, k[9], dot2_k(D1, k[8], rnd));
+    a[5] = dot2_k(D0, k[11], dot2_k(D1, k[10], rnd));
+    a[3] = dot2_k(D0, k[13], dot2_k(D1, k[12], rnd));
+    a[1] = dot2_k(D0, k[15], dot2_k(D1, k[14], rnd));
 }
 // (hi >> 17, lo >> 17) as packed int16 (lo in the low half): the two high halves side by side, each shifted once more
 __device__ __forceinline__ uint32_t pack_sh17(int hi, int lo) {
@@ -732,6 +764,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // first group on a SIMD holds the low slots); the groups take turns at raised priority, one macroblock at a time.
     const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
     const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
+    const unsigned prio_bits4 = prio_bits * 0x01010101u;      // the pattern four times over: bit (iteration & 31) is bit (iteration & 7)
     if (tid == 0) { L.scalars[S_HINT] = 0; L.scalars[S_SHARED_HINT] = (int)pro_shared_hint; }
     unsigned pass_sum = 0, pass_hist[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_start = 0, t_mark = 0, phase_ticks[6] = {0, 0, 0, 0, 0, 0};
@@ -1160,6 +1193,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // DCT of the macroblock whose pixel bytes are (b_lo, b_hi)
         auto dct_mb = [&](const uint4& ts, uint32_t b_lo, uint32_t b_hi) {
             int d[8];
+            // the column pass's coefficient pairs: one scalar load from the kernel argument segment, issued here, waited for where
+            // the column pass starts (the row pass in between hides it).  The compiler does not know the load is in flight: between
+            // the two statements nothing may touch the registers -- tests/test_kernel_resources.py reads the disassembly for that.
+            u32x16 ck;
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(ck) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(FrameJob, col_k)));
             {
                 // -- row pass on the matrix pipe: every lane hands in its own row vector (lane = (block, row); lanes 48..63 idle
                 //    columns), and gets back four outputs of vector lane & 31 and four of vector 32 + (lane & 31)
@@ -1172,8 +1210,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             wave_sync();
             if (lane < 48) {
                 // -- column pass: lane = (block, column); 8 int16 of that column are contiguous
-                const uint4 q = *(const uint4*)&tileT[blk * kTileStride + r8 * 8];
-                fdct8_col_acc(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), d);
+                // (the column's read and the wait for it AND for the coefficients in one statement: one s_waitcnt)
+                uint4 q;
+                asm volatile("ds_read2_b64 %0, %2 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(q), "+s"(ck) : "v"((uint32_t)(uintptr_t)&tileT[blk * kTileStride + r8 * 8]) : "memory");
+                fdct8_col_acc_k(q.x, q.y, __builtin_amdgcn_alignbit(q.w, q.w, 16), __builtin_amdgcn_alignbit(q.z, q.z, 16), ck, d);
                 // -- column 0 holds the block's DC term in d[0] (as an accumulator: value << 17).  v2: its quantised value
                 //    (mdec.c:447-453) takes its place at scan position 0 and travels with the block's DC slot in the code list.
                 //    v3: the DC codes come from the pre-pass (DPCM chain), position 0 holds 0.  Either way lane 0 is never treated
@@ -1348,7 +1389,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (emit_scale && n_pass > 1) {
                 // a further emitting pass rebuilds the staging area
                 for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-                if (tid == 0) { L.scalars[S_STG_NEXT] = 0; L.scalars[S_OVERFLOW] = 0; }
+                if (tid == 0) L.scalars[S_STG_NEXT] = 0;
                 group_sync(5);
             }
             // Macroblocks are handed out by ticket (an LDS counter): wavefronts that draw cheap macroblocks draw more, and all of
@@ -1357,15 +1398,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // its own; from then on it draws the ticket after next while it works, so that neither the counter's round trip nor
             // the order look-up (a scalar load) nor the pixel fetch of the next macroblock is waited for.
             // A table entry is what the loop needs of its macroblock, ready made (psxhip_mdec_pass_table): x = fy * 8 W (the
-            // macroblock row's byte offset in the chroma plane; luma lanes shift it) | valid << 31, y = fx * 16 | encode-order
+            // macroblock row's byte offset in the chroma plane; luma lanes shift it) | valid << 31, y = fx * 16 | 4 * encode-order
             // index << 16.  An entry without a macroblock is all zero: its fetch reads macroblock (0, 0), no select needed.
+            // The table ends with one all-zero entry: a ticket past the end (the last draws of a pass; the checkpoint's "stop")
+            // is clamped onto it -- one scalar min and a load at a 32-bit byte offset, no compare, branch or 64-bit address.
+            typedef const char __attribute__((address_space(4))) * OrderBytes;
             typedef const uint32_t __attribute__((address_space(4))) * OrderPtr;
-            const OrderPtr order_w = (OrderPtr)(uintptr_t)job.order;
-            auto order_at = [&](int t) -> uint2 { return make_uint2(order_w[2 * t], order_w[2 * t + 1]); };
+            const OrderBytes order_b = (OrderBytes)(uintptr_t)job.order;
             const int n_tickets = job.trips * kWavesPerGroup;
+            auto order_at = [&](int t) -> uint2 {
+                const uint32_t byte = min((uint32_t)t, (uint32_t)n_tickets) * 8u;
+                const OrderPtr e = (OrderPtr)(order_b + byte);
+                return make_uint2(e[0], e[1]);
+            };
             int cur_t = wid, nxt_t = wid + kWavesPerGroup;
             uint2 cur_o = order_at(cur_t);
-            uint2 nxt_o = nxt_t < n_tickets ? order_at(nxt_t) : make_uint2(0u, 0u);
+            uint2 nxt_o = order_at(nxt_t);
             fetch_at(cur_o.x & 0x7FFFFFFFu, cur_o.y & 0xFFFFu);
             const QuantK kc = make_quant(lc.quant, count_scale ? count_scale : 1);
             const QuantK ke = make_quant(lc.quant, emit_scale ? emit_scale : 1);
@@ -1373,16 +1421,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             int acc_edef = 0;            // per lane: deficit over the emitted codes
             int n_codes = 0;             // wave-uniform: codes emitted (AC codes + DC slots)
             int emit_bits = 0, mb_done = 0;  // wave-uniform
-            unsigned emit_sq = 0, emit_s1 = 0;   // wave-uniform: sums of x^2 and x, x = macroblock stream bits >> 2 (see the checkpoint)
-            bool dense_prev = false;         // wave-uniform: the previous macroblock's list at the count scale was too long to walk
+            int prev_len = 0;                // wave-uniform: length of the previous macroblock's list at the count scale (above 128: too long to walk)
             // compaction threshold of this lane: smallest |n| that quantises to non-zero at the list's scale
             // (|n| >= t  <=>  (unsigned)(n + t - 1) >= 2 t - 1: one add and one compare, no absolute value)
             const uint32_t thr_low = (uint32_t)((lc.quant * (count_scale ? count_scale : 1) + 1) >> 1);
             const uint32_t thr_emit = (uint32_t)((lc.quant * (emit_scale ? emit_scale : 1) + 1) >> 1);
             // (lane 0 -- scan position 0, the block's DC slot -- is always kept: its span is 0, and x + off >= 0 always holds)
-            const uint32_t low_off = thr_low - 1u, low_span = lane == 0 ? 0u : 2u * thr_low - 1u;
+            // (the list's scale: the count scale when the pass counts, else the emit scale -- chosen here, once per pass)
+            const uint32_t thr_list = count_scale ? thr_low : thr_emit;
+            const uint32_t low_off = thr_list - 1u, low_span = lane == 0 ? 0u : 2u * thr_list - 1u;
             const uint32_t emit_off = thr_emit - 1u, emit_span = lane == 0 ? 0u : 2u * thr_emit - 1u;
-            auto lane_tag_now = [&]() -> uint32_t { return (uint32_t)in_loop(lane) << 17; };
             // per-wavefront totals -> LDS (also used by the checkpoint: flushing resets the partial sums)
             auto flush = [&]() {
                 if (count_scale) {
@@ -1396,10 +1444,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         atomicAdd(&L.scalars[S_EMIT_BITS], emit_bits);
                         atomicAdd(&L.scalars[S_EMIT_D], td);
                         atomicAdd(&L.scalars[S_NNZ], tc - 6 * mb_done);      // AC codes = all codes - the DC slots
-                        atomicAdd((unsigned*)&L.scalars[S_CK_SQ], emit_sq);
-                        atomicAdd((unsigned*)&L.scalars[S_CK_S1], emit_s1);
                     }
-                    acc_edef = 0; n_codes = 0; emit_bits = 0; emit_sq = 0; emit_s1 = 0;
+                    acc_edef = 0; n_codes = 0; emit_bits = 0;
                 }
                 if (lane == 0) atomicAdd(&L.scalars[S_CK_DONE], mb_done);
                 mb_done = 0;
@@ -1423,7 +1469,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     flush();
                     int arrived = 0;
                     if (lane == 0) arrived = atomicAdd(&L.scalars[S_CK_WAVES], 1);
-                    if (__builtin_amdgcn_readfirstlane(arrived) == kWavesPerGroup - 1 && lane == 0) {
+                    const bool judge = __builtin_amdgcn_readfirstlane(arrived) == kWavesPerGroup - 1;
+                    // the spread of the sample: sums of x and x^2, x = a macroblock's stream bits >> 2, over the tickets before the
+                    // mark -- read back from the records the macroblocks left (stage_alloc), by the whole judging wavefront, once
+                    // per pass (kept as running sums they were six scalar instructions in every macroblock of every wavefront)
+                    unsigned ck_s1 = 0, ck_sq = 0;
+                    if (judge && emit_scale) {
+                        for (int t = lane; t < check_t; t += 64) {
+                            const OrderPtr oe = (OrderPtr)(order_b + (uint32_t)t * 8u);
+                            if ((int)oe[0] < 0) {
+                                const unsigned x = *(const uint32_t*)((const char*)L.rec + (oe[1] >> 16)) >> 18;
+                                ck_s1 += x;
+                                ck_sq += x * x;
+                            }
+                        }
+                        ck_s1 = (unsigned)wave::reduce_add((int)ck_s1);
+                        ck_sq = (unsigned)wave::reduce_add((int)ck_sq);
+                    }
+                    if (judge && lane == 0) {
                         const int done = L.scalars[S_CK_DONE];
                         long long pa = 0, pb = 0;
                         if (count_scale) pa = (long long)L.scalars[S_CNT_F] * nmb / done + fixed_bits;
@@ -1436,8 +1499,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         // over a fixed 5 % margin, stable content is unaffected).
                         int margin = (limit_bits - fixed_bits) / 50;
                         if (emit_scale && done > 1 && done < nmb) {
-                            const float n = (float)done, mean = (float)(unsigned)L.scalars[S_CK_S1] / n;      // of x = bits >> 2
-                            float var = (float)(unsigned)L.scalars[S_CK_SQ] / n - mean * mean;
+                            const float n = (float)done, mean = (float)ck_s1 / n;      // of x = bits >> 2
+                            float var = (float)ck_sq / n - mean * mean;
                             var = var > 0.0f ? var : 0.0f;
                             const float se = 4.0f * __builtin_sqrtf(var * n * (1.0f - n / (float)nmb)) * ((float)nmb / n);
                             margin = (int)(se * (float)job.ck_margin * 0.001f);
@@ -1453,13 +1516,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (WAVES == kWavesSmall) {
                     // (s_setprio takes an immediate, so this IS a branch; written out, because the compiler's own if / else around
                     //  the two builtins came to eight scalar instructions and two branches per macroblock)
-                    const unsigned pbit = prio_bits >> (it & 7);
-                    asm volatile("s_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\ts_setprio 1\n2:" : : "s"(pbit) : "scc");
+                    //  (s_bitcmp1 takes the bit number from a register's low five bits)
+                    asm volatile("s_bitcmp1_b32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\ts_setprio 1\n2:" : : "s"(prio_bits4), "s"(it) : "scc");
                 }
                 int drawn = 0;
                 if (lane == 0) drawn = atomicAdd(&L.scalars[S_MB_NEXT], 1);
                 const bool valid = (int)cur_o.x < 0;
-                const int mbe = (int)(cur_o.y >> 16);
+                const uint32_t rec_byte = cur_o.y >> 16;        // 4 * the macroblock's encode-order index: its record's byte offset
+                const int mbe = (int)(rec_byte >> 2);
                 {
                     const uint4 ts = L.tab_sel[lane];
                     uint32_t b_lo, b_hi;
@@ -1471,12 +1535,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 cur_t = nxt_t;
                 cur_o = nxt_o;
                 nxt_t = __builtin_amdgcn_readfirstlane(drawn);
-                nxt_o = nxt_t < n_tickets ? order_at(nxt_t) : make_uint2(0u, 0u);
+                nxt_o = order_at(nxt_t);
                 if (!valid) continue;
                 mb_done++;
                 if (kStopAfter == 1 || kStopAfter == 2) continue;
 
-                const int cs = count_scale;
                 int ci[6];       // this lane's coefficient (scan position = lane) of each block; lane 0 (the DC slot) holds 0
 #pragma unroll
                 for (int b = 0; b < 6; b++) ci[b] = (int)tileZ[b * kZStride + lc.zsrc];
@@ -1489,7 +1552,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     for (int b = 0; b < 6; b++) cff[b] = lane == 0 ? 0.0f : (float)ci[b];
                     const int a = count_mb(cff, kc, lc, L.ac_len16);
                     acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
-                } else {
+                    continue;
+                }
+                // An emitting pass, with (cs) or without counting at the scale below: the macroblock's work is instantiated for
+                // each -- "does this pass count" is then no test at all, and what remains of the dense-macroblock logic is two
+                // compares of scalar integers (run-time flags here were some twenty scalar instructions and branches per macroblock).
+                constexpr std::true_type yes{};
+                constexpr std::false_type no{};
+                auto emit_mb = [&](auto cs_tag) {
+                    constexpr bool cs = decltype(cs_tag)::value;
                     // ---- 1. compaction.  At the scales that matter only a few of a block's 64 coefficients are non-zero, so
                     //      everything expensive (VLC look-ups, bit positions, LDS writes) runs on a COMPACTED list, built once
                     //      per macroblock at the pass's LOWER scale (a coefficient that is non-zero at a coarser scale is non-zero
@@ -1499,37 +1570,59 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     //      A macroblock that is dense at the count scale (a list of more than two chunks) is listed again at the
                     //      emit scale and counted in place (count_mb): walking a long list costs more than it saves.
                     auto build_list = [&](uint32_t off, uint32_t span) -> int {
-                        // (everything but the store itself is computed by all lanes: the masked region is one instruction, and the
-                        //  mask is the compare's own result -- lane 0 keeps by construction, see low_span)
-                        int c = 0;                             // wave-uniform
-                        const uint32_t lane_tag = lane_tag_now();
-#pragma unroll
-                        for (int b = 0; b < 6; b++) {
-                            const bool keep = (uint32_t)ci[b] + off >= span;
-                            const uint64_t mk = wave::ballot(keep);
-                            uint32_t* const slot = &clist[c + wave::popc_below(mk)];
-                            const uint32_t entry = ((uint32_t)ci[b] & 0x1FFFFu) | lane_tag;
-                            if (keep) *slot = entry;
-                            c += (int)__builtin_popcountll(mk);
-                        }
-                        return c;
+                        // Written out: per block add, compare, (independent) entry, the mask into exec, rank (mbcnt), address, store,
+                        // exec back, population count, running byte address -- 6 vector + 4 scalar instructions and no branch, where
+                        // the compiler's version of the same six lines was 6 + 6 and a branch around every store (scalar
+                        // instructions weigh as much as vector ones here).  gfx950 wants two wait states between
+                        // a VALU write of vcc and a VALU read of it as an operand (v_mbcnt): the entry and the saveexec stand there.
+                        // Lane 0 keeps by construction (see low_span); the tag is made here from the lane number (no register
+                        // held across the loop).
+                        const uint32_t cb0 = (uint32_t)(uintptr_t)clist;                 // LDS byte address (wave-uniform)
+                        uint32_t cb = cb0, t, e, tag, n;
+                        unsigned long long sv;
+#define PSX_LIST_BLOCK(CI)                                                \
+                            "v_add_u32 %[t], %[off], %[" CI "]\n\t"                \
+                            "v_cmp_ge_u32 vcc, %[t], %[span]\n\t"                  \
+                            "v_and_or_b32 %[e], %[" CI "], %[m17], %[tag]\n\t"      \
+                            "s_and_saveexec_b64 %[sv], vcc\n\t"                    \
+                            "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"               \
+                            "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"            \
+                            "v_lshl_add_u32 %[t], %[t], 2, %[cb]\n\t"              \
+                            "ds_write_b32 %[t], %[e]\n\t"                          \
+                            "s_mov_b64 exec, %[sv]\n\t"                            \
+                            "s_bcnt1_i32_b64 %[n], vcc\n\t"                        \
+                            "s_lshl2_add_u32 %[cb], %[n], %[cb]\n\t"
+                        asm volatile("v_lshlrev_b32 %[tag], 17, %[lane]\n\t"
+                                     PSX_LIST_BLOCK("c0") PSX_LIST_BLOCK("c1") PSX_LIST_BLOCK("c2")
+                                     PSX_LIST_BLOCK("c3") PSX_LIST_BLOCK("c4") PSX_LIST_BLOCK("c5")
+                                     : [cb] "+s"(cb), [t] "=&v"(t), [e] "=&v"(e), [tag] "=&v"(tag), [n] "=&s"(n), [sv] "=&s"(sv)
+                                     : [off] "v"(off), [span] "v"(span), [m17] "s"(0x1FFFFu), [lane] "v"(lane),
+                                       [c0] "v"(ci[0]), [c1] "v"(ci[1]), [c2] "v"(ci[2]), [c3] "v"(ci[3]), [c4] "v"(ci[4]), [c5] "v"(ci[5])
+                                     : "vcc", "scc", "memory");
+#undef PSX_LIST_BLOCK
+                        // (the count from a statement whose ONLY output is scalar by constraint: out of the statement above, or as
+                        //  plain arithmetic on the LDS address, the compiler took it for lane-dependent -- and every branch on it)
+                        asm("s_sub_u32 %0, %1, %2\n\ts_lshr_b32 %0, %0, 2" : "=s"(n) : "s"(cb), "s"(cb0) : "scc");
+                        return (int)n;
                     };
                     // (built straight away; only after a dense macroblock the next one is sized up first -- busy content comes in runs)
-                    bool dense = false, list_low = false;      // list_low: the list holds the count scale's codes
+                    bool dense = false;
                     int count = 0;
-                    if (cs && dense_prev) {
+                    if (cs && prev_len > 128) {      // (prev_len: the previous macroblock's list length at the count scale, the six DC slots included)
                         int n_low = 0;
 #pragma unroll
                         for (int b = 0; b < 6; b++) n_low += (int)__builtin_popcountll(wave::ballot((uint32_t)ci[b] + low_off >= low_span));
-                        dense = n_low > 128;      // (the six DC slots included)
+                        prev_len = n_low;
+                        dense = n_low > 128;
                     }
                     if (!dense) {
-                        count = cs ? build_list(low_off, low_span) : build_list(emit_off, emit_span);
-                        list_low = cs != 0;
-                        dense = cs && count > 128;
+                        count = build_list(low_off, low_span);
+                        if (cs) {
+                            prev_len = count;
+                            dense = count > 128;
+                        }
                     }
-                    dense_prev = dense;
-                    if (kStopAfter == 3) { asm volatile("" :: "s"(count)); wave_sync(); continue; }
+                    if (kStopAfter == 3) { asm volatile("" :: "s"(count)); wave_sync(); return; }
                     if (dense) {
                         float cff[6];
 #pragma unroll
@@ -1538,7 +1631,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         acc_cnt += (a & 0xFF) | ((a >> 8) << 16);
                         wave_sync();
                         count = build_list(emit_off, emit_span);
-                        list_low = false;
                     }
                     wave_sync();
 
@@ -1638,31 +1730,29 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             len += add;
                         }
                     };
-                    constexpr std::true_type yes{};
-                    constexpr std::false_type no{};
                     // staging for a macroblock of `mb_bits` bits (all six end-of-block codes included): returns its bit position
                     bool have_room = true;
                     auto stage_alloc = [&](uint32_t mb_bits) -> uint32_t {
                         const int ndw = (int)((mb_bits + 31u) >> 5);
                         int off = 0;
-                        if (lane == 0) off = atomicAdd(&L.scalars[S_STG_NEXT], ndw);
-                        off = __builtin_amdgcn_readfirstlane(off);
-                        have_room = off + ndw <= job.stg_words;
                         if (lane == 0) {
-                            L.rec[mbe] = ((uint32_t)off & 0xFFFFu) | (mb_bits << 16);
-                            if (!have_room) L.scalars[S_OVERFLOW] = 1;
+                            // (one masked region: the allocation and the macroblock's record -- position | bits << 16, both below 2^16)
+                            off = atomicAdd(&L.scalars[S_STG_NEXT], ndw);
+                            *(uint32_t*)((char*)L.rec + rec_byte) = (uint32_t)off | (mb_bits << 16);
                         }
+                        off = __builtin_amdgcn_readfirstlane(off);
+                        have_room = off + ndw <= job.stg_words;      // (a pass that ran out of room is seen at its end: S_STG_NEXT > stg_words)
                         emit_bits += (int)mb_bits;
-                        emit_sq += (mb_bits >> 2) * (mb_bits >> 2);
-                        emit_s1 += mb_bits >> 2;
                         return (uint32_t)off * 32u;
                     };
                     // (lanes without a code stay out: an OR of nothing is still an LDS atomic on a neighbour's dword -- tried, +57 % bank
                     //  conflict cycles and 12 % slower on 640x480, whose chunks have more idle lanes)
                     auto put_codes = [&](uint32_t pos, int len, uint32_t code) {
-                        if (have_room && len) put_bits(L.stg, pos, len, code);
+                        if (have_room) {        // (wave-uniform: a branch, not a mask)
+                            if (len) put_bits(L.stg, pos, len, code);
+                        }
                     };
-                    bool low = list_low;
+                    bool low = cs && !dense;       // the list holds the count scale's codes
                     if (low && count > 64) {
                         // A long list at the count scale (busy macroblocks, fine scales): count its codes chunk by chunk and keep
                         // only the entries that are still non-zero at the emit scale -- typically fewer than half.  They are
@@ -1733,7 +1823,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         }
                     }
                     wave_sync();   // the list is overwritten by the next macroblock's tiles
-                }
+                };
+                if (count_scale) emit_mb(yes);
+                else emit_mb(no);
             }
             // outside the passes a group runs short, latency-bound phases (decisions, scans, merge): let them cut ahead of the
             // partner group's VALU stream instead of queueing behind it
@@ -1787,7 +1879,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_PASS_COUNT] = np.count_scale;
                     L.scalars[S_PASS_EMIT] = np.emit_scale;
                     L.scalars[S_DONE] = np.done;
-                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0;
                     L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                     (void)hand_on(np);
@@ -1799,7 +1891,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (emit_scale) {
                     const int tb = L.scalars[S_EMIT_BITS] + 10;        // + end-of-frame code
                     mdec_search_note(st, emit_scale, tb, tb - L.scalars[S_EMIT_D], limit_bits);
-                    st.staged = L.scalars[S_OVERFLOW] ? 0 : emit_scale;
+                    st.staged = L.scalars[S_STG_NEXT] > job.stg_words ? 0 : emit_scale;       // (the staging area ran out during this pass)
                     L.scalars[S_TOTAL_BITS] = tb;
                 }
                 const MdecPass np = mdec_search_next(st, guess, limit_bits, fixed_bits);
@@ -1809,7 +1901,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 L.scalars[S_DONE] = np.done;
                 L.scalars[S_RESULT] = st.best;
                 if (!np.done) {
-                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0; L.scalars[S_CK_SQ] = 0; L.scalars[S_CK_S1] = 0;
+                    L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
                     if (np.emit_scale) { L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0; }
                     (void)hand_on(np);
@@ -2158,11 +2250,12 @@ extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t
     return n;
 }
 
-// ... and the same order as the kernel reads it: per ticket {fy * 8 W | valid << 31, fx * 16 | encode-order index << 16} (an entry
-// without a macroblock is all zero).  Returns the number of tickets.
-extern "C" int psxhip_mdec_pass_table(int width, int height, int large, uint32_t* out /* [2 * n] */, int cap) {
+// ... and the same order as the kernel reads it: per ticket {fy * 8 W | valid << 31, fx * 16 | 4 * encode-order index << 16} (an entry
+// without a macroblock is all zero), followed by one all-zero entry (cap > n).  Returns the number of tickets n.
+extern "C" int psxhip_mdec_pass_table(int width, int height, int large, uint32_t* out /* [2 * (n + 1)] */, int cap) {
     const int n = psxhip_mdec_pass_order(width, height, large, nullptr, 0);
     if (!out) return n;
+    if (cap > n) { out[2 * n] = 0u; out[2 * n + 1] = 0u; }        // the entry tickets past the end are clamped onto
     uint32_t* o = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
     if (!o) return -1;
     (void)psxhip_mdec_pass_order(width, height, large, o, n);
@@ -2171,7 +2264,7 @@ extern "C" int psxhip_mdec_pass_table(int width, int height, int large, uint32_t
         if (o[t] == kNoMb) { out[2 * t] = 0u; out[2 * t + 1] = 0u; continue; }
         const uint32_t fx = o[t] & 0xFFu, fy = o[t] >> 8;
         out[2 * t] = (fy * 8u * (uint32_t)width) | 0x80000000u;
-        out[2 * t + 1] = (fx * 16u) | ((fx * (uint32_t)ny + fy) << 16);
+        out[2 * t + 1] = (fx * 16u) | ((fx * (uint32_t)ny + fy) * 4u << 16);
     }
     free(o);
     return n;
@@ -2212,6 +2305,7 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.stats = a->d_stats;
     job.prio_pattern = a->prio_pattern;
     job.ck_margin = a->ck_margin > 0 ? a->ck_margin : 800;
+    { constexpr ColCoeffs ck = col_coeffs(); for (int i = 0; i < 16; i++) job.col_k[i] = ck.k[i]; }
     job.trips = (job.nmb + waves_ - 1) / waves_;
     job.it_step = pick_it_step(job.trips);
     job.order = a->d_order;

@@ -259,12 +259,13 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     const bool both = !c->large && psxhip_mdec_lds_bytes(c->nmb, c->out_words, c->stg_words, 1) <= lds_cu && !getenv("PSXHIP_MDEC_NO_SMALL_BATCH_SHAPE");
     for (int shape = c->large; shape <= (both ? 1 : c->large); shape++) {
         const int n = psxhip_mdec_pass_table(width, height, shape, nullptr, 0);
-        uint32_t* h = (uint32_t*)malloc((size_t)n * 2 * sizeof(uint32_t));
+        const size_t tab_bytes = ((size_t)n + 1) * 2 * sizeof(uint32_t);          // n tickets + the all-zero entry behind them
+        uint32_t* h = (uint32_t*)malloc(tab_bytes);
         if (!h) { psxhip_set_error("out of host memory"); return PSXHIP_ENOMEM; }
-        if (psxhip_mdec_pass_table(width, height, shape, h, n) != n) { free(h); psxhip_set_error("out of host memory"); return PSXHIP_ENOMEM; }
+        if (psxhip_mdec_pass_table(width, height, shape, h, n + 1) != n) { free(h); psxhip_set_error("out of host memory"); return PSXHIP_ENOMEM; }
         uint32_t** dst = shape == c->large ? &c->d_order : &c->d_order_large;
-        hipError_t e = hipMalloc((void**)dst, (size_t)n * 2 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(*dst, h, (size_t)n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice);
+        hipError_t e = hipMalloc((void**)dst, tab_bytes);
+        if (e == hipSuccess) e = hipMemcpy(*dst, h, tab_bytes, hipMemcpyHostToDevice);
         free(h);
         if (e != hipSuccess) { psxhip_set_error("pass order table: %s", hipGetErrorString(e)); return PSXHIP_ENOMEM; }
     }

@@ -44,7 +44,7 @@ int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int cap);
-int psxhip_mdec_pass_table(int width, int height, int large, uint32_t *out /* [2 * n] */, int cap);
+int psxhip_mdec_pass_table(int width, int height, int large, uint32_t *out /* [2 * (n + 1)] */, int cap);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
 hipError_t psxhip_mdec_stage_in_launch(const void *src_mapped, void *d_dst, size_t bytes, void *stream);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
