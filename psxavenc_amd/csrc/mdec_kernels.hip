@@ -426,6 +426,11 @@ __device__ __forceinline__ int in_loop(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// Ballots written as the compare itself.  __builtin_amdgcn_ballot_w64(a != b) folds into one v_cmp only while that compare has no
+// other user; one that is also a predicate elsewhere is turned into 0 / 1 and compared again (two more vector instructions).
+__device__ __forceinline__ uint64_t ballot_ne0(int x) { uint64_t m; asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(x)); return m; }
+__device__ __forceinline__ uint64_t ballot_eq0(int x) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(x)); return m; }
+template <int C> __device__ __forceinline__ uint64_t ballot_eq(int x) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, %2, %1" : "=s"(m) : "v"(x), "n"(C)); return m; }
 
 // wave-level ordering point for LDS traffic between lanes of the same wavefront
 __device__ __forceinline__ void wave_sync() {
@@ -1651,10 +1656,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const bool live = i < count;
                         uint32_t e = clist[i];                                  // (always inside the wavefront's tiles: i < 384)
                         e = live ? e : (63u << 17);                             // dead lanes: |n| = 0 at scan position 63
-                        const int k = (int)((e >> 17) & 63u);
-                        const bool neg = (e & 0x10000u) != 0;
+                        const int k = (int)__builtin_amdgcn_ubfe(e, 17, 6);
+                        const uint32_t negbit = __builtin_amdgcn_ubfe(e, 16, 1);      // the sign as a number: only the escape code needs it as a predicate
                         const bool is_dc = k == 0;
-                        const uint64_t dcm = wave::ballot(k == 0);        // (taken next to the compare: it folds into it)
+                        const uint64_t dcm = CODEC == 0 ? 0ull : wave::ballot(k == 0);        // (v3: the DC slots' block numbers)
                         const bool is_ac = live && !is_dc;
                         const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
                         cnt16 = 0;
@@ -1675,31 +1680,47 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             }
                             if (!single) kcarry_a = __builtin_amdgcn_readlane(k, 63);
                         }
-                        int q = quant_mag(magf, ek);                           // <= 2048
+                        const int q = quant_mag(magf, ek);                     // <= 2048
                         if (low) {
-                            // previous surviving entry
-                            const uint64_t sm = wave::ballot(q != 0) | dcm;   // (dead lanes: |n| = 0 at position 63)
+                            // Previous surviving entry.  A list at the count scale is ONE chunk (longer ones are recompacted first), so
+                            // the slots behind it are free: every survivor leaves its scan position at slot (its rank among the
+                            // survivors) and reads its predecessor's one slot down -- rank (mbcnt), one address, a masked store and a
+                            // load, where the mask-below-me / count-leading-zeros / bpermute route was thirteen vector instructions.
+                            // Rank 0 is lane 0, the macroblock's first DC slot: what it reads is never used.
+                            static_assert(single || !low, "a list at the count scale is one chunk");
+                            const uint64_t sm = ballot_ne0(q) | ballot_eq0(k);     // (dead lanes: |n| = 0 at position 63)
                             ncodes = (int)__builtin_popcountll(sm);
-                            const uint64_t below = sm & ((1ull << in_loop(lane)) - 1ull);
-                            const int ps = 63 - __clzll((long long)below);         // -1 when there is none in this chunk
-                            const int kp = __builtin_amdgcn_ds_bpermute(ps << 2, k);
-                            kprev = below ? kp : kcarry_b;
-                            if (!single && sm) kcarry_b = __builtin_amdgcn_readlane(k, 63 - __builtin_clzll(sm));
-                            is_last = lane == 63 - __builtin_clzll(sm);       // (a list at the count scale is one chunk; DC slots survive: sm != 0)
+                            const uint32_t kslot = (uint32_t)(uintptr_t)(clist + 64 + wave::popc_below(sm));
+                            unsigned long long sv;
+                            asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(sv) : "s"(sm), "v"(kslot), "v"(k) : "memory");          // survivors only
+                            typedef const uint32_t __attribute__((address_space(3))) * LdsWord;
+                            kprev = (int)*(LdsWord)(uintptr_t)(kslot - 4u);                      // (a wavefront's LDS accesses complete in order)
+                            is_last = lane == 63 - __builtin_clzll(sm);       // (DC slots survive: sm != 0)
                         } else {
                             is_last = i == count - 1;
                             kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
                             if (!single) kcarry_b = __builtin_amdgcn_readlane(k, 63);
                             ncodes = count - base < 64 ? count - base : 64;      // a list at the emit scale: every entry is a code
                         }
-                        const int lim = neg ? 512 : 510;               // level clamp, mdec.c:260-267
-                        q = q > lim ? lim : q;
-                        const int run = is_ac ? k - kprev - 1 : 0;
-                        const uint32_t entry = L.ac_code[lut_index(is_ac ? q : 0, run)];
-                        const int sl = neg ? -q : q;
-                        const uint32_t esc = (1u << 16) | ((uint32_t)run << 10) | ((uint32_t)sl & 0x3FFu);   // mdec.c:258
+                        // one index, one select: row min(q, 41), column run = k - kprev - 1 (silent lanes: entry 0, no bits)
+                        const int run_raw = k + ~kprev;
+                        const unsigned qrow = (unsigned)q > (unsigned)(BS_LUT_MAX_LEVEL + 1) ? (unsigned)(BS_LUT_MAX_LEVEL + 1) : (unsigned)q;
+                        const int li = (int)__umul24(qrow, (unsigned)BS_LUT_W) + run_raw;
+                        const uint32_t entry = L.ac_code[is_ac ? li : 0];
                         len = (int)(entry >> 24);
-                        code = len == BS_ESCAPE_BITS ? esc : ((entry & 0x1FFFFu) | (neg ? 1u : 0u));
+                        code = (entry & 0x1FFFFu) | negbit;
+                        if (ballot_eq<BS_ESCAPE_BITS>(len)) {
+                            // (rare, so behind a wave-uniform branch) escape: 6 bits 000001, run, 10-bit level (mdec.c:258) clamped to
+                            // -512 .. 510 (mdec.c:260-267; only the escape's payload ever sees a level that large)
+                            asm volatile("; escape codes");     // (an asm statement keeps the branch around this block: left alone, the
+                                                                //  compiler runs the eight instructions under an empty mask instead)
+                            const int lim = 510 + 2 * (int)negbit;
+                            const int qc = q > lim ? lim : q;
+                            const int sl = (qc ^ -(int)negbit) + (int)negbit;
+                            const uint32_t esc = (1u << 16) | ((uint32_t)run_raw << 10) | ((uint32_t)sl & 0x3FFu);
+                            code = len == BS_ESCAPE_BITS ? esc : code;
+                        }
                         deficit = (int)((entry >> BS_LUT_DEFICIT_SHIFT) & 0xFu);
                         if (CODEC == 0) {
                             // v2 DC slot: the entry carries the quantised DC; 10 bits (mdec.c:451-453), every slot but the

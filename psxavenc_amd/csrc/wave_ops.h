@@ -15,8 +15,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ int dpp_or_zero(int x) {
-    // lanes whose source is out of range or masked read 0 (old = 0, bound_ctrl = 0)
-    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, false);
+    // lanes whose source is out of range or masked read 0: with every row and bank enabled the hardware's own zero fill
+    // (bound_ctrl) does it and no register has to hold the 0; masked forms keep old = 0
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, ROW_MASK == 0xF && BANK_MASK == 0xF);
 }
 
 // Inclusive prefix sum over the 64 lanes.
