@@ -530,6 +530,19 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t pos, int len,
     atomicOr(&words[w], hi);
     if (lo) atomicOr(&words[w + 1], lo);
 }
+// The same into the LDS staging area at dword `base_dw` (wave-uniform) + bit `bit`: the address written out -- one scalar
+// shift-add for the base, a shift and a shift-add per lane (the compiler's own version of "(bit >> 5) * 4" is shift, mask, add).
+__device__ __forceinline__ void put_bits_lds(uint32_t* stg, uint32_t base_dw, uint32_t bit, int len, uint32_t v) {
+    typedef uint32_t __attribute__((address_space(3))) * LdsWord;
+    uint32_t sb, a;
+    asm("s_lshl2_add_u32 %0, %2, %3\n\tv_lshrrev_b32 %1, 5, %4\n\tv_lshl_add_u32 %1, %1, 2, %0"
+        : "=&s"(sb), "=&v"(a) : "s"(base_dw), "s"((uint32_t)(uintptr_t)stg), "v"(bit) : "scc");
+    const LdsWord wp = (LdsWord)(uintptr_t)a;
+    const uint32_t top = v << (32 - len);
+    const uint32_t hi = top >> (bit & 31), lo = __builtin_amdgcn_alignbit(top, 0u, bit & 31);
+    __hip_atomic_fetch_or(wp, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lo) __hip_atomic_fetch_or(wp + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // Per-lane constants of the AC path: lane k owns zig-zag position k.
 struct LaneConst {
@@ -1661,7 +1674,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         const bool is_dc = k == 0;
                         const uint64_t dcm = CODEC == 0 ? 0ull : wave::ballot(k == 0);        // (v3: the DC slots' block numbers)
                         const bool is_ac = live && !is_dc;
-                        const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
+                        // the coefficient (an int16: the tiles hold 16-bit values, bit 16 repeats the sign) as a float, one instruction:
+                        // the convert sign-extends the entry's low half itself (SDWA); the quantiser takes |.|
+                        float magf;
+                        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(magf) : "v"(e));
                         cnt16 = 0;
                         int kprev;
                         bool is_last;
@@ -1676,7 +1692,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                                 ck.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, kc.inv)));
                                 ck.bias = __builtin_fmaf(0.25f, ck.inv, 0.5f);
                                 const int qa = quant_mag(magf, ck);
-                                cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
+                                // bits | deficit << 16, spread here (carried out of the chunk as the 16-bit table entry it was masked again)
+                                uint32_t lw = L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
+                                asm("" : "+v"(lw));          // (pins the zero-extension to the load: used in a later block it is a separate mask)
+                                cnt16 = (int)__builtin_amdgcn_perm(0u, lw, 0x0C010C00u);
                             }
                             if (!single) kcarry_a = __builtin_amdgcn_readlane(k, 63);
                         }
@@ -1696,7 +1715,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                                          : "=&s"(sv) : "s"(sm), "v"(kslot), "v"(k) : "memory");          // survivors only
                             typedef const uint32_t __attribute__((address_space(3))) * LdsWord;
                             kprev = (int)*(LdsWord)(uintptr_t)(kslot - 4u);                      // (a wavefront's LDS accesses complete in order)
-                            is_last = lane == 63 - __builtin_clzll(sm);       // (DC slots survive: sm != 0)
+                            int last = 63 - __builtin_clzll(sm);              // (DC slots survive: sm != 0)
+                            asm("" : "+s"(last));                             // (the subtraction stays scalar: one vector compare)
+                            is_last = lane == last;
                         } else {
                             is_last = i == count - 1;
                             kprev = __builtin_amdgcn_update_dpp(kcarry_b, k, 0x138, 0xF, 0xF, false);
@@ -1726,8 +1747,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             // v2 DC slot: the entry carries the quantised DC; 10 bits (mdec.c:451-453), every slot but the
                             // macroblock's first also carries the previous block's end-of-block code
                             if (is_dc) {
-                                const uint32_t dcv10 = e & 0x3FFu;
-                                code = i != 0 ? dcv10 | (2u << 10) : dcv10;
+                                const uint32_t eob = i != 0 ? 2u << 10 : 0u;       // (a per-lane constant of a one-chunk list: one and-or)
+                                code = (e & 0x3FFu) | eob;
                                 len = i != 0 ? 12 : 10;
                             }
                         } else {
@@ -1764,13 +1785,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         off = __builtin_amdgcn_readfirstlane(off);
                         have_room = off + ndw <= job.stg_words;      // (a pass that ran out of room is seen at its end: S_STG_NEXT > stg_words)
                         emit_bits += (int)mb_bits;
-                        return (uint32_t)off * 32u;
+                        return (uint32_t)off;            // (in dwords: base and bit offset stay apart, put_codes)
                     };
                     // (lanes without a code stay out: an OR of nothing is still an LDS atomic on a neighbour's dword -- tried, +57 % bank
                     //  conflict cycles and 12 % slower on 640x480, whose chunks have more idle lanes)
-                    auto put_codes = [&](uint32_t pos, int len, uint32_t code) {
+                    auto put_codes = [&](uint32_t base_dw, uint32_t bit, int len, uint32_t code) {
                         if (have_room) {        // (wave-uniform: a branch, not a mask)
-                            if (len) put_bits(L.stg, pos, len, code);
+                            if (len) put_bits_lds(L.stg, base_dw, bit, len, code);
                         }
                     };
                     bool low = cs && !dense;       // the list holds the count scale's codes
@@ -1814,10 +1835,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         if (low) chunk(yes, yes, yes, 0, len, code, deficit, cnt16, nc);
                         else chunk(no, no, yes, 0, len, code, deficit, cnt16, nc);
                         const int incl = wave::inclusive_scan_add(len);
-                        const uint32_t pos = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
-                        put_codes(pos + (uint32_t)(incl - len), len, code);
+                        const uint32_t base_dw = stage_alloc((uint32_t)__builtin_amdgcn_readlane(incl, 63));
+                        put_codes(base_dw, (uint32_t)(incl - len), len, code);
                         acc_edef += deficit;
-                        acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
+                        acc_cnt += cnt16;
                         n_codes += nc;
                     } else {
                         // longer lists: add up the lengths first (the allocation needs the macroblock's total), then write
@@ -1828,7 +1849,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             chunk(no, no, no, base, len, code, deficit, cnt16, nc);      // (a list of several chunks is at the emit scale: see the recompaction above)
                             lsum += len;
                         }
-                        uint32_t pos = stage_alloc((uint32_t)wave::reduce_add(lsum));
+                        const uint32_t base_dw = stage_alloc((uint32_t)wave::reduce_add(lsum));
+                        uint32_t pos = 0;
                         kcarry_a = 0;
                         kcarry_b = 0;
                         bcarry = 0;
@@ -1837,7 +1859,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             uint32_t code;
                             chunk(no, no, no, base, len, code, deficit, cnt16, nc);
                             const int incl = wave::inclusive_scan_add(len);
-                            put_codes(pos + (uint32_t)(incl - len), len, code);
+                            put_codes(base_dw, pos + (uint32_t)(incl - len), len, code);
                             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                             acc_edef += deficit;
                             n_codes += nc;
