@@ -272,7 +272,7 @@ def _main():
                          "8 channels x 60 min).  Explicit flags below override a preset's values")
     ap.add_argument("--launches-per-step", type=int, default=0,
                     help="a step = this many back-to-back launches, cycling over --batches distinct batches (default: enough for "
-                         "--steps 20 to time over ten seconds of GPU work: 3400 launches of 1000 320x240 frames)")
+                         "--steps 20 to time over ten seconds of GPU work: 4800 launches of 1000 320x240 frames)")
     ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
     ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
@@ -348,7 +348,7 @@ def _main():
     nb = max(1, args.batches)
     lps = args.launches_per_step
     if lps <= 0:        # >= ~0.5 s of GPU work per step at the measured rates: 20 steps time > 10 s (a 5-second utilisation sampler cannot miss it)
-        lps = max(nb, min(3400, int(round(3400 * (1000 * 115200) / float(max(n, 1) * fsz)))))
+        lps = max(nb, min(4800, int(round(4800 * (1000 * 115200) / float(max(n, 1) * fsz)))))
     ns = max(1, args.streams)
     encs = [MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank) for _ in range(ns)]
     enc = encs[0]

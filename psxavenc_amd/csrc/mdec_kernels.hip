@@ -1806,10 +1806,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             const bool live = i < count;
                             uint32_t e = clist[i];
                             e = live ? e : (63u << 17);
-                            const int k = (int)((e >> 17) & 63u);
+                            const int k = (int)__builtin_amdgcn_ubfe(e, 17, 6);
                             const bool is_dc = k == 0;
                             const bool is_ac = live && !is_dc;
-                            const float magf = (float)(((int)(e << 15)) >> 15);      // signed (v_bfe_i32); the quantiser takes |.|  [not __builtin_amdgcn_sbfe: hipcc 7.2 folds fabs(float(sbfe)) into an unsigned convert]
+                            float magf;                                            // (as in chunk(): one SDWA convert)
+                            asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(magf) : "v"(e));
                             QuantK ck, ek;
                             ck.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, kc.inv)));
                             ck.bias = __builtin_fmaf(0.25f, ck.inv, 0.5f);
@@ -1818,11 +1819,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             const int ka = __builtin_amdgcn_update_dpp(kcarry, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
                             kcarry = __builtin_amdgcn_readlane(k, 63);
                             const int qa = quant_mag(magf, ck);
-                            const int cnt16 = (int)L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
-                            acc_cnt += (int)__builtin_amdgcn_perm(0u, (uint32_t)cnt16, 0x0C010C00u);     // bits | deficit << 16
+                            uint32_t lw = L.ac_len16[lut_index(is_ac ? qa : 0, is_ac ? k - ka - 1 : 0)];
+                            asm("" : "+v"(lw));
+                            acc_cnt += (int)__builtin_amdgcn_perm(0u, lw, 0x0C010C00u);     // bits | deficit << 16
                             const int qe = quant_mag(magf, ek);
-                            const uint64_t sm = wave::ballot(qe != 0) | wave::ballot(k == 0);      // (dead lanes: |n| = 0 at position 63)
-                            if ((qe != 0) | (k == 0)) clist[sc + wave::popc_below(sm)] = e;
+                            const uint64_t sm = ballot_ne0(qe) | ballot_eq0(k);      // (dead lanes: |n| = 0 at position 63)
+                            const uint32_t slot = (uint32_t)(uintptr_t)(clist + sc + wave::popc_below(sm));
+                            unsigned long long sv;
+                            asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(sv) : "s"(sm), "v"(slot), "v"(e) : "memory");          // survivors only
                             sc += (int)__builtin_popcountll(sm);
                         }
                         wave_sync();
