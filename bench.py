@@ -815,7 +815,7 @@ def bench_xacd(args):
     init = np.zeros((2 * n_ch, 2), np.int32)
     torch.cuda.synchronize()
 
-    chunk_units, warmup_units = adpcm.pick_chunking(int(chains["n_units"].sum()) * world)
+    chunk_units, warmup_units = adpcm.pick_chunking(int(chains["n_units"].sum()))       # this GPU's share: chunks are cut to fill ITS wavefront slots
 
     # the session (chunk tables, per-unit state storage) is set up once; a step starts the encode over on it
     sess = adpcm.AdpcmSession(pcm.reshape(-1), chains, base, 4, 4, d_units=d_units, lead_units=lead, chunk_units=chunk_units,

@@ -247,14 +247,32 @@ def xa_assemble_device(d_units, n_sectors, settings, first_lba=0, d_eof=None):
     return out
 
 
-def pick_chunking(total_units):
-    """(chunk_units, warmup_units) for speculate-and-verify: few verify passes vs enough chunks to fill the GPU
-    (same rule as psxhip_audio_api.cpp; tools/gpu_adpcm_sweep.py)."""
+def pick_chunking(total_units, rows=5, n_cu=None):
+    """(chunk_units, warmup_units) for speculate-and-verify: few verify passes vs enough chunks to fill the GPU; large jobs get
+    the chunk length at which every wavefront slot (8 per SIMD) holds exactly one wavefront of `rows` chunks (same rule as
+    psxhip_audio_api.cpp; tools/gpu_adpcm_sweep.py, tools/gpu_xacd_chunk_sweep.sh).  rows: chains per wavefront, 5 for XA
+    (4 filters), 4 for SPU (5 filters)."""
+    import os
+    if os.environ.get("PSXHIP_ADPCM_CHUNK"):          # experiments only (tools/gpu_xacd_chunk_sweep.sh)
+        return int(os.environ["PSXHIP_ADPCM_CHUNK"]), int(os.environ.get("PSXHIP_ADPCM_WARM", "128"))
+    if n_cu is None:
+        n_cu = 256
+        try:
+            import torch
+            if torch.cuda.is_available():
+                n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        except Exception:
+            pass
+    per_round = 32 * n_cu * rows
+    fill = -(-total_units // per_round)
+    if fill >= 1024:
+        rounds = -(-fill // 4096)
+        return -(-total_units // (per_round * rounds)), 64
     c = total_units // 8192
     p = 64
-    while p * 2 <= c and p < 4096:
+    while p * 2 <= c and p < 1024:
         p *= 2
-    return p, (128 if p >= 4096 else 32 if p >= 1024 else 16)
+    return p, (32 if p >= 1024 else 16)
 
 
 class AdpcmSession:

@@ -127,6 +127,10 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
 // (prev1, prev2) advance to the winner's decoded state when `unit_live`.  Returns true on the winning lane,
 // whose `header` and pk_lds[w * 64 + lane] (w = 0..6: four codes per word) then hold the unit's record.  The trial
 // loop is kept rolled (codes parked in LDS) so that the whole encoder needs few registers.
+// A row's staged samples: 28 + padding to 32 ints, rows 33 ints apart -- every lane of a row reads the same sample (a broadcast),
+// the rows read different addresses, and at a stride of 32 ints rows 0, 2, 4 met in one LDS bank (PMC: five conflict cycles per LDS
+// instruction of the speculating kernel); 33 puts the wavefront's rows into different banks for every sample index.
+constexpr int kXsStride = 33;
 template <int ROW>
 __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, bool unit_live, int lane, int& prev1,
                                             int& prev2, uint32_t& header, uint32_t* pk_lds /* [7][64] per wavefront */) {
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job)
     n_max = max(n_max, __shfl_xor(n_max, 32, 64));
 
     const int16_t* src = job.samples + ch.sample_offset;
-    __shared__ int xs_all[4][32];
+    __shared__ int xs_all[4][kXsStride];
     __shared__ uint32_t pk_lds[7 * 64];
     int* xs = xs_all[lane >> 4];
 
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(64) void adpcm_call_kernel(const CallJob job) {
     const int lane = (int)(threadIdx.x & 63);
     const Candidate cd = make_candidate<16>(lane, job.filter_count, job.range);
     __shared__ __attribute__((aligned(16))) int16_t stage[kCallStageMax];
-    __shared__ int xs_all[4][32];
+    __shared__ int xs_all[4][kXsStride];
     __shared__ uint32_t pk_lds[7 * 64];
 
     const int16_t* base = job.samples;
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     int n_warm = active ? warm : 0;
     int w_max = n_warm;
     w_max = wave_max(w_max);
-    __shared__ int xs_all[64 / ROW + 1][32];
+    __shared__ int xs_all[64 / ROW + 1][kXsStride];
     __shared__ uint32_t pk_lds[7 * 64];
     int* xs = xs_all[row];
     for (int t = 0; t < w_max; t++) {
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     // younger is in flight -- and only then this unit's record and state are stored.  The loop never waits for a store.
     // (Loading the stored state where it is compared cost two exposed global round trips per unit: 2.3 us instead of 1.)
     bool running = active;
-    __shared__ int xs_alt[64 / ROW + 1][32];
+    __shared__ int xs_alt[64 / ROW + 1][kXsStride];
     int* xs_a = xs;
     int* xs_b = xs_alt[row];
     UnitFetch nxt = fetch_unit<ROW>(src, ch, first, running && 0 < n_run, lane);

@@ -27,13 +27,27 @@ constexpr int kChunkedThreshold = 4096;
 // chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass, and tonal material
 // does not fall into the same state within a thousand units), short enough that there are >= ~8 k chunks -- 1600+
 // wavefronts -- to fill 256 CUs (tools/gpu_adpcm_sweep.py: 13 M units, tonal: chunks of 1024 are 14 % faster than 512;
-// 78 M units: 4096 is 8 % faster than 1024; noise: within 3 %); warm-up 16 .. 128 units
-inline void pick_chunking(long long total_units, int* chunk_units, int* warmup_units) {
+// noise: within 3 %); warm-up 16 .. 64 units.  Jobs that are large enough for it get the length at which every wavefront
+// slot of the GPU (8 per SIMD) holds exactly ONE wavefront of `rows` chunks: the encoder is a dependent chain per unit, so a
+// SIMD with four wavefronts runs its VALU at 84 % and one with eight at ~100 %, and a launch of 3.7 wavefronts per SIMD ends
+// when the SIMDs that drew four do (config 5, 78 M units on one GPU: 1899 instead of 4096 units per chunk, 21.3 -> 24.4 M
+// sectors/s, still two verify passes; 1266: three passes, 950: four -- tools/gpu_xacd_chunk_sweep.sh).
+inline void pick_chunking(long long total_units, int rows, int device, int* chunk_units, int* warmup_units) {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu < 1) n_cu = 256;
+    const long long per_round = 32ll * n_cu * rows;                        // chunks in flight when every slot holds a wavefront
+    const long long fill = (total_units + per_round - 1) / per_round;
+    if (fill >= 1024) {
+        const long long rounds = (fill + 4095) / 4096;
+        *chunk_units = (int)((total_units + per_round * rounds - 1) / (per_round * rounds));
+        *warmup_units = 64;
+        return;
+    }
     long long c = total_units / 8192;
     int p = 64;
-    while (p * 2 <= c && p < 4096) p *= 2;
+    while (p * 2 <= c && p < 1024) p *= 2;
     *chunk_units = p;
-    *warmup_units = p >= 4096 ? 128 : p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 1024 either
+    *warmup_units = p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 1024 either
 }
 
 // Device scratch of the host-buffer entry points.  The reference calls psx_audio_spu_encode once per 28 samples and
@@ -232,7 +246,7 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
         // long streams: parallel along time as well (speculate-and-verify; same bytes as the serial chain kernel)
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
         int chunk_units, warmup_units;
-        pick_chunking((long long)n_units * n_streams, &chunk_units, &warmup_units);
+        pick_chunking((long long)n_units * n_streams, 4, device, &chunk_units, &warmup_units);
         rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), n_streams, 5, 4,
                                                 d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), chunk_units, warmup_units, 0, st);
         if (rc < 0) return rc;
@@ -369,7 +383,7 @@ extern "C" int psxhip_xa_encode_streams_host_flags(int device, int format, int s
     if (units_per_chain >= kChunkedThreshold) {
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
         int chunk_units, warmup_units;
-        pick_chunking((long long)units_per_chain * (long long)chains.size(), &chunk_units, &warmup_units);
+        pick_chunking((long long)units_per_chain * (long long)chains.size(), 5, device, &chunk_units, &warmup_units);
         rc = psxhip_adpcm_encode_chains_chunked(device, d_s.as<int16_t>(), chains.data(), base.data(), (int)chains.size(), 4, bits,
                                                 d_st.as<psxhip_adpcm_state_t>(), d_u.as<uint8_t>(), chunk_units, warmup_units, 0, st);
         if (rc < 0) return rc;
