@@ -701,28 +701,40 @@ struct XaJob {
 
 __device__ __forceinline__ uint8_t to_bcd(int v) { return (uint8_t)(v + (v / 10) * 6); }
 
-// EDC tables, the same for every sector: built once on the host (xa_tables()), copied into LDS by every workgroup.
-//   [0..255]    reflected CRC-32 table for polynomial 0xD8018001 (cdrom.c:28-41)
-//   [256 + 32 k + b]  CRC state (1 << b) advanced over 10 * 2^k zero bytes, k = 0..7
+// EDC tables, the same for every sector: built once on the host (xa_tables()).
+//   [0..255]          reflected CRC-32 table for polynomial 0xD8018001 (cdrom.c:28-41), copied into LDS by every workgroup
+//   [256 + 32 j + b]  CRC state (1 << b) advanced over 40 * 2^j zero bytes, j = 0..5 (read through the scalar cache)
 __constant__ uint32_t c_xa_tables[256 + 8 * 32];
+
+constexpr int kEdcChunk = 40;                       // bytes per lane of the wavefront that computes the EDC
+constexpr int kEdcSpan = 0x91C;                     // sector bytes 0x10 .. 0x92B (cdrom.c:102-110)
+constexpr int kEdcPad = 64 * kEdcChunk - kEdcSpan;  // 228 zero bytes in front: they change nothing (zero init, no final xor)
+static_assert(kEdcPad >= 0 && kEdcPad % 4 == 0 && kEdcChunk % 4 == 0, "the lanes' chunks are whole dwords of the sector");
+
+// CRC state c advanced over 40 * 2^J zero bytes: the xor of the table rows of its set bits (the CRC is linear over GF(2))
+template <int J>
+__device__ __forceinline__ uint32_t edc_advance(uint32_t c) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int bit = 0; bit < 32; bit++) r ^= c_xa_tables[256 + 32 * J + bit] & (uint32_t)(((int)(c << (31 - bit))) >> 31);
+    return r;
+}
 
 __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
     __shared__ __attribute__((aligned(16))) uint8_t sec[2352];
     __shared__ uint32_t crc_tab[256];
-    __shared__ uint32_t crc_part[256];
-    __shared__ uint32_t zmat[8][32];   // zmat[k][b]: CRC state (1 << b) advanced over 10 * 2^k zero bytes
     const int tid = (int)threadIdx.x;
     const int s = (int)blockIdx.x;
     const bool four = job.bits == 4;
     const int upg = four ? 8 : 4;                 // sound units per group
     const int sector_size = job.format == 0 ? 2336 : 2352;
+    uint32_t* const sec32 = (uint32_t*)sec;
 
     crc_tab[tid] = c_xa_tables[tid];
-    ((uint32_t*)zmat)[tid] = c_xa_tables[256 + tid];
-    for (int i = tid; i < 2352 / 4; i += 256) ((uint32_t*)sec)[i] = 0u;
+    for (int i = tid; i < 2352 / 4; i += 256) sec32[i] = 0u;
     __syncthreads();
 
-    if (tid == 0) {
+    if (tid == 255) {
         if (job.format == 1) {       // psx_cdrom_init_sector, mode 2 (cdrom.c:55-74)
             for (int i = 1; i <= 10; i++) sec[i] = 0xFF;
             const int lba = job.first_lba + s + 150;
@@ -740,60 +752,82 @@ __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
 
     // sound groups: 18 x 128 bytes at sector offset 0x18 (adpcm.c:193-233,311-322)
     const uint8_t* rec0 = job.units + (size_t)s * 18 * upg * kRecordBytes;
-    for (int i = tid; i < 18 * 128; i += 256) {
-        const int g = i >> 7, b = i & 127;
-        const uint8_t* gr = rec0 + (size_t)g * upg * kRecordBytes;
-        uint8_t v;
-        if (b < 16) {
-            // header bytes: 4-bit: units {0,1,2,3} at 0..3 and 4..7, units {4..7} at 8..11 and 12..15;
-            // 8-bit: units 0..3 at 0..3 and 4..7, bytes 8..15 are never written by the reference (stay 0)
-            const int unit = four ? ((b & 3) | ((b & 8) >> 1)) : (b & 3);
-            v = (four || b < 8) ? gr[unit * kRecordBytes] : 0;
-        } else {
-            const int w = (b - 16) >> 2, col = (b - 16) & 3;          // sample index, byte column
-            if (four) {
-                const uint8_t lo = gr[(2 * col) * kRecordBytes + 4 + w];
-                const uint8_t hi = gr[(2 * col + 1) * kRecordBytes + 4 + w];
-                v = (uint8_t)((lo & 0x0F) | (hi << 4));
+    if (four) {
+        // 4-bit: sample w of the group's 8 units is the 4 bytes (u0 | u1 << 4, u2 | u3 << 4, u4 | u5 << 4, u6 | u7 << 4) at group
+        // byte 16 + 4 w.  A record holds its 28 codes as 7 dwords behind the header dword: thread (group, q) reads dword q of
+        // the 8 records, pairs the nibbles of all four samples at once and transposes the 4 x 4 bytes -- 16 contiguous
+        // output bytes from 8 dword loads (byte by byte it was 32 byte loads and 16 byte stores).
+        if (tid < 18 * 7) {
+            const int g = tid / 7, q = tid - g * 7;
+            const uint32_t* gr = (const uint32_t*)(rec0 + (size_t)g * 8 * kRecordBytes) + 1 + q;
+            uint32_t p[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t lo = gr[(2 * c) * (kRecordBytes / 4)], hi = gr[(2 * c + 1) * (kRecordBytes / 4)];
+                p[c] = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);          // byte j: column c of sample 4 q + j
+            }
+            // transpose: out[j] = (p0.j, p1.j, p2.j, p3.j)
+            const uint32_t a0 = __builtin_amdgcn_perm(p[1], p[0], 0x05010400u), a1 = __builtin_amdgcn_perm(p[1], p[0], 0x07030602u);   // (p0.0 p1.0 p0.1 p1.1), (p0.2 p1.2 p0.3 p1.3)
+            const uint32_t b0 = __builtin_amdgcn_perm(p[3], p[2], 0x05010400u), b1 = __builtin_amdgcn_perm(p[3], p[2], 0x07030602u);
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(b0, a0, 0x05040100u);      // (p0.0 p1.0 p2.0 p3.0)
+            o.y = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+            o.z = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+            o.w = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+            uint32_t* dst = sec32 + (0x18 + g * 128 + 16 + 16 * q) / 4;        // (0x18 + 128 g + 16 + 16 q: a multiple of 8)
+            dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w;
+        } else if (tid >= 128 && tid < 128 + 18 * 2) {
+            // header bytes: units {0,1,2,3} at 0..3 and 4..7, units {4..7} at 8..11 and 12..15
+            const int g = (tid - 128) >> 1, half = (tid - 128) & 1;
+            const uint8_t* gr = rec0 + (size_t)g * 8 * kRecordBytes + (size_t)half * 4 * kRecordBytes;
+            const uint32_t h = (uint32_t)gr[0] | (uint32_t)gr[kRecordBytes] << 8 | (uint32_t)gr[2 * kRecordBytes] << 16 | (uint32_t)gr[3 * kRecordBytes] << 24;
+            uint32_t* dst = sec32 + (0x18 + g * 128 + 8 * half) / 4;
+            dst[0] = h; dst[1] = h;
+        }
+    } else {
+        for (int i = tid; i < 18 * 128; i += 256) {
+            const int g = i >> 7, b = i & 127;
+            const uint8_t* gr = rec0 + (size_t)g * upg * kRecordBytes;
+            uint8_t v;
+            if (b < 16) {
+                // 8-bit: units 0..3 at 0..3 and 4..7, bytes 8..15 are never written by the reference (stay 0)
+                v = b < 8 ? gr[(b & 3) * kRecordBytes] : 0;
             } else {
+                const int w = (b - 16) >> 2, col = (b - 16) & 3;          // sample index, byte column
                 v = gr[col * kRecordBytes + 4 + w];
             }
+            sec[0x18 + i] = v;
         }
-        sec[0x18 + i] = v;
     }
     __syncthreads();
 
-    // form-2 EDC over sector bytes 0x10 .. 0x92B (0x91C = 2332 bytes) -> 0x92C (cdrom.c:102-110).
-    // The CRC has zero init and no final xor, so it is linear over GF(2): the CRC of the span is the xor of
-    // the CRCs of its chunks, each advanced over the zero bytes that follow it.  The span is viewed as
-    // 256 chunks of 10 bytes (228 leading zero bytes of padding change nothing); thread t owns chunk t and
-    // advances its partial by 10 * (255 - t) zero bytes using the power-of-two "append zeros" matrices zmat.
-    {
-        constexpr int kChunk = 10, kTotal = 0x91C, kPad = 256 * kChunk - kTotal;
+    // form-2 EDC over sector bytes 0x10 .. 0x92B (2332 bytes) -> 0x92C (cdrom.c:102-110).
+    // The CRC has zero init and no final xor, so it is linear over GF(2): the CRC of the span is the xor of the CRCs of its
+    // chunks, each advanced over the zero bytes that follow it.  ONE wavefront does it: lane t runs the table CRC over chunk t
+    // of 40 bytes (64 x 40 = the span behind 228 zero bytes of padding), then six rounds of a binary tree -- lane t takes
+    // its partial advanced over 40 * 2^j zero bytes xor the partial 2^j lanes up -- leave the sector's EDC in lane 0.
+    // (Before: 256 chunks of 10 bytes, every thread advancing its partial to the END of the span through up to eight
+    // bit-matrix products out of LDS -- four wavefronts x 8 products of 32 conditional xors where one wavefront x 6 does.)
+    if (tid < 64) {
         uint32_t c = 0;
-        for (int i = 0; i < kChunk; i++) {
-            const int at = tid * kChunk + i - kPad;
-            if (at >= 0) c = (c >> 8) ^ crc_tab[(c ^ sec[0x10 + at]) & 0xFF];
+        const int d0 = tid * (kEdcChunk / 4) - kEdcPad / 4;        // first dword of the chunk, relative to sector byte 0x10
+#pragma unroll
+        for (int i = 0; i < kEdcChunk / 4; i++) {
+            const int d = d0 + i;
+            c ^= d >= 0 ? sec32[4 + d] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) c = (c >> 8) ^ crc_tab[c & 0xFF];
         }
-        const int tail_chunks = 255 - tid;
-        for (int k = 0; k < 8; k++) {
-            if ((tail_chunks >> k) & 1) {
-                uint32_t r = 0;
-                for (int bit = 0; bit < 32; bit++)
-                    if ((c >> bit) & 1u) r ^= zmat[k][bit];
-                c = r;
-            }
-        }
-        crc_part[tid] = c;
-        __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if (tid < off) crc_part[tid] ^= crc_part[tid + off];
-            __syncthreads();
-        }
-        if (tid < 4) sec[0x92C + tid] = (uint8_t)(crc_part[0] >> (8 * tid));
+        c = edc_advance<0>(c) ^ (uint32_t)__shfl_down((int)c, 1, 64);
+        c = edc_advance<1>(c) ^ (uint32_t)__shfl_down((int)c, 2, 64);
+        c = edc_advance<2>(c) ^ (uint32_t)__shfl_down((int)c, 4, 64);
+        c = edc_advance<3>(c) ^ (uint32_t)__shfl_down((int)c, 8, 64);
+        c = edc_advance<4>(c) ^ (uint32_t)__shfl_down((int)c, 16, 64);
+        c = edc_advance<5>(c) ^ (uint32_t)__shfl_down((int)c, 32, 64);
+        if (tid == 0) sec32[0x92C / 4] = c;
         // psx_audio_xa_encode_finalize (adpcm.c:334-340) ORs EOF into both subheader copies AFTER the EDC was
-        // computed and does not refresh it; kept that way for byte parity.
-        if (tid == 4 && (job.eof_flags ? job.eof_flags[s] != 0 : (s < 32 && ((job.eof_bits >> s) & 1u)))) {
+        // computed and does not refresh it; kept that way for byte parity.  (Same wavefront, behind its reads of the span.)
+        if (tid == 1 && (job.eof_flags ? job.eof_flags[s] != 0 : (s < 32 && ((job.eof_bits >> s) & 1u)))) {
             sec[18] |= 0x80;
             sec[22] = sec[18];
         }
@@ -1183,7 +1217,7 @@ static int xa_tables(int device) {
     uint32_t* z = t + 256;
     for (int b = 0; b < 32; b++) {
         uint32_t v = 1u << b;
-        for (int i = 0; i < 10; i++) v = (v >> 8) ^ t[v & 0xFF];
+        for (int i = 0; i < kEdcChunk; i++) v = (v >> 8) ^ t[v & 0xFF];
         z[b] = v;
     }
     for (int k = 1; k < 8; k++)
