@@ -459,10 +459,12 @@ def _main():
         import oracle_lib as O
         per = max(1, min(args.check_frames, n * len(ress)) // len(ress))
         ok, checked = True, 0
+        # (--streams S > 1: an output buffer per STREAM; stream 0's buffer holds the batch of its last launch)
+        last_b0 = (((args.steps * lps - 1) // ns) * ns) % nb
         for b, r in enumerate(ress):
             idx = np.linspace(0, n - 1, min(per, n)).astype(np.int64)
             tidx = torch.from_numpy(idx).to(dev)
-            fr = d_batches[b][tidx].cpu().numpy()
+            fr = d_batches[b if ns == 1 else last_b0][tidx].cpu().numpy()
             want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
             got = d_outs[b if ns == 1 else 0][tidx].cpu().numpy()[:, :budget]
             ok = ok and bool(rc == 0 and np.array_equal(got, want) and np.array_equal(r[idx], want_res))
