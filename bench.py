@@ -119,6 +119,11 @@ def _gather_ranks(dist, xdev, values):
     return [o.tolist() for o in outs]
 
 
+AUDIO_KINDS = {0: "two tones + noise floor (tonal: a wrong start state survives thousands of units -- the hard case)",
+               1: "quiet tone + noise", 2: "white noise, full scale (states coincide within a few units)", 3: "silence",
+               4: "one tone, half scale", 5: "gated tone + noise floor (bursts and silence)"}
+
+
 def _stats(xs):
     xs = sorted(xs)
     n = len(xs)
@@ -273,6 +278,8 @@ def _main():
     ap.add_argument("--launches-per-step", type=int, default=0,
                     help="a step = this many back-to-back launches, cycling over --batches distinct batches (default: enough for "
                          "--steps 20 to time over ten seconds of GPU work: 4800 launches of 1000 320x240 frames)")
+    ap.add_argument("--audio-kind", type=int, default=0, help="xacd: synthetic material (psxhip_synth_pcm_device kind): 0 two tones + noise "
+                    "floor -- tonal, start-state guesses do not converge, the hard case and the default; 2 white noise; 5 gated tone")
     ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
     ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
@@ -754,6 +761,9 @@ def _secondary_configs(args):
         ("sbs_v3_1250", [sys.executable, me, "--config", "sbs_v3", "--total-frames", "1250", "--steps", "8", "--warmup", "2", "--no-secondary",
                          "--cpu-seconds", "4"] + seed),
         ("xacd_config5", [sys.executable, me, "--config", "xacd", "--steps", "20", "--warmup", "2", "--cpu-seconds", "5"] + seed),
+        # the same job on other material (config 5's number is set by its tonal test signal: one chain that does not converge)
+        ("xacd_config5_white_noise", [sys.executable, me, "--config", "xacd", "--audio-kind", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"] + seed),
+        ("xacd_config5_gated_tone", [sys.executable, me, "--config", "xacd", "--audio-kind", "5", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"] + seed),
         ("strcd_config3", [sys.executable, me, "--config", "strcd", "--steps", "150", "--warmup", "5", "--cpu-seconds", "4"] + seed),
         ("rccl_world_size_1", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                                "--master-port", str(port), me, "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2", "--warmup", "1",
@@ -807,7 +817,7 @@ def bench_xacd(args):
     pcm = torch.empty((n_ch, n_frames * 2), dtype=torch.int16, device=dev)
     for c in range(n_ch):
         for side in range(2):
-            synth.pcm_device(args.seed, 2 * c + side, (sec0 - lead_sec) * sps, n_frames, 0, device=local_rank,
+            synth.pcm_device(args.seed, 2 * c + side, (sec0 - lead_sec) * sps, n_frames, args.audio_kind, device=local_rank,
                              out=pcm[c][side:], pitch=2)
     chains = adpcm.make_chains([(c * n_frames * 2 + lead_sec * sps * 2 + side) for c in range(n_ch) for side in range(2)], 2,
                                sec_cnt * sps, sec_cnt * units_per_sector_chain, unit_stride=2)
@@ -869,6 +879,7 @@ def bench_xacd(args):
             "config": {"workload": "xacd: %d XA channels x stereo x %.0f s @ 37800 Hz, 4-bit, %d sectors per channel, time-sharded x%d"
                                    % (n_ch, n_sectors * sps / 37800.0, n_sectors, world),
                        "preset": args.config, "baseline_config": args.baseline_config,
+                       "material": AUDIO_KINDS.get(args.audio_kind, str(args.audio_kind)),
                        "verify_passes_last_step": passes, "chunk_units": chunk_units, "warmup_units": warmup_units, "realtime_factor": round(value * sps / 37800.0 / n_ch, 1)},
             "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
