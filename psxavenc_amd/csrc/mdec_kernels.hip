@@ -2281,20 +2281,36 @@ static int pick_it_step(int trips) {
 }
 
 // The order in which a pass's tickets visit the macroblocks: ticket t = (round r = t / waves, slot w = t % waves) visits
-// raster index w + ((r * step) % trips) * waves, with step coprime to trips and close to 0.382 trips -- any run of
-// tickets, in particular the first quarter the checkpoint looks at, is spread evenly over the frame.  Entries past the
-// last macroblock (the final round may be partial) hold kNoMb.  Returns the number of tickets (trips * waves).
+// raster index w + seq[r] * waves.  For the rounds of the first quarter -- what the checkpoint looks at -- seq[r] =
+// (r * step) % trips with step coprime to trips and close to 0.382 trips: they are spread evenly over the frame.  Entries
+// past the last macroblock (the final round may be partial) hold kNoMb.  Returns the number of tickets (trips * waves).
 extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t* out, int cap) {
     const int waves = large ? kWavesLarge : kWavesSmall;
     const int nx = width / 16, ny = height / 16, nmb = nx * ny;
     const int trips = (nmb + waves - 1) / waves, step = pick_it_step(trips);
     const int n = trips * waves;
     if (!out) return n;
+    // The rounds before the checkpoint's mark (trips / 4 of them) are spread evenly over the frame, the rest follow in raster
+    // order: a round's twelve macroblocks read 192-byte pieces of pixel rows, memory is fetched in 128-byte granules, and with
+    // EVERY round scattered the half-used granules at a round's ends were gone from L2 before the neighbouring round came
+    // (fetch 141 MB per 1000 frames of 320x240 against 115 MB of pixels; 123 MB with three quarters of the rounds in raster order).  Scattering all rounds in runs
+    // of 3 or 5 neighbours instead (tools/gpu_pass_run_sweep.sh) saves as much but changes what the checkpoint samples -- three
+    // adjacent macroblock rows are no sample of a picture -- and moved noisy content by -12 .. +14 %.
+    int* seq = (int*)malloc((size_t)trips * sizeof(int));      // ticket round -> raster round (a permutation)
+    char* used = (char*)calloc((size_t)trips, 1);
+    if (!seq || !used) { free(seq); free(used); return -1; }
+    const int spread = trips >= 8 ? trips >> 2 : trips;       // (the kernel's check_t: no checkpoint below 8 rounds)
+    int k = 0;
+    for (int r = 0; r < spread; r++) { seq[k] = (r * step) % trips; used[seq[k++]] = 1; }
+    for (int rr = 0; rr < trips; rr++) if (!used[rr]) seq[k++] = rr;
+    free(used);
     for (int t = 0; t < n && t < cap; t++) {
         const int r = t / waves, w = t % waves;
-        const int m = w + ((r * step) % trips) * waves;
+        const int rr = seq[r];
+        const int m = w + rr * waves;
         out[t] = m < nmb ? (uint32_t)(m % nx) | (uint32_t)(m / nx) << 8 : kNoMb;
     }
+    free(seq);
     return n;
 }
 

@@ -7,7 +7,7 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.5"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.6"
 
 #ifdef __cplusplus
 extern "C" {

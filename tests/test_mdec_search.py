@@ -135,3 +135,10 @@ def test_pass_order_visits_every_macroblock_once_and_spreads_the_first_quarter(w
             assert bands.min() * 3 >= bands.max(), bands
         else:
             assert (bands > 0).sum() >= min(rounds, 3), bands      # a handful of rounds cannot be even, only scattered
+        # ... and the rounds behind the quarter mark follow in raster order (neighbouring rounds share the 128-byte fetch
+        # granules at their ends: scattered, those were fetched twice)
+        rest = o[(n // waves // 4) * waves:]
+        first_of_round = rest[::waves]
+        first_of_round = first_of_round[first_of_round != 0xFFFF].astype(np.int64)
+        raster = (first_of_round >> 8) * nx + (first_of_round & 0xFF)
+        assert (np.diff(raster) > 0).all()
