@@ -287,6 +287,9 @@ def _main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--budget", type=int, default=None, help="frame_max_size = sbs alignment (args.c:184)")
     ap.add_argument("--codec", type=int, default=None, help="0 = BS v2, 1 = v3, 2 = v3dc")
+    ap.add_argument("--budget-cycle", default=None,
+                    help="sbs: per-frame budgets cycling over this comma-separated list instead of one uniform --budget, e.g. "
+                         "16128,18144,18144,18144 = what encode_sector_str asks for at 320x240 15 fps 2x speed (mdec.c:768-775; config 3's video leg alone, device-resident)")
     ap.add_argument("--amp", type=int, default=None, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="sbs: contexts / streams the launches are dealt over (default 1: in-order launches on one stream)")
@@ -345,6 +348,9 @@ def _main():
     from psxavenc_amd.parallel import shard_range
 
     w, h, budget = args.width, args.height, args.budget
+    cycle = [int(x) for x in args.budget_cycle.split(",")] if args.budget_cycle else None
+    if cycle:
+        budget = max(cycle)
     strong = args.total_frames > 0
     if strong:          # the job's frames are fixed; every rank takes its contiguous share
         first, n = shard_range(args.total_frames, rank, world)
@@ -372,6 +378,8 @@ def _main():
     d_batches = [synth.frames_device(w, h, args.seed + b, first, n, args.amp, device=local_rank) for b in range(nb)]
     d_frames = d_batches[0]
     ostride = (budget + 3) & ~3
+    # --budget-cycle: frame i of the job (not of the rank's share) gets cycle[i % len]: any rank can budget its own range
+    d_sizes = torch.tensor([cycle[(first + i) % len(cycle)] for i in range(n)], dtype=torch.int32, device=dev) if cycle else None
     d_outs = [torch.zeros((n, ostride), dtype=torch.uint8, device=dev) for _ in range(max(ns, nb))]
     d_ress = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(max(ns, nb))]
     # --streams 1 (default): every launch on torch's current stream, one context.  --streams S: S contexts on S streams,
@@ -384,7 +392,7 @@ def _main():
         i = k % ns
         b = k % nb
         o = b if ns == 1 else i          # one output buffer per batch (in-order launches) or per stream (overlapping launches)
-        encs[i].encode_frames_device(d_batches[b], budget, d_out=d_outs[o], d_results=d_ress[o], stream=streams[i])
+        encs[i].encode_frames_device(d_batches[b], budget if d_sizes is None else d_sizes, d_out=d_outs[o], d_results=d_ress[o], stream=streams[i])
 
     for k in range(args.warmup * lps):
         launch(k)
@@ -421,6 +429,8 @@ def _main():
     kernel_ms = [a.elapsed_time(b) / (lps if per_step else 1) for a, b in ev]      # per launch
     kstat = _stats(kernel_ms)
     alg_bytes = (fsz + budget) * n                       # per launch: NV21 read + frame_max_size written, per frame
+    if cycle:
+        alg_bytes = fsz * n + sum(cycle[(first + i) % len(cycle)] for i in range(n))
     achieved_local = alg_bytes / (kstat["mean"] * 1e-3) / 1e9
     if ns > 1:      # launches overlap: a launch's own duration says little, the aggregate rate is what the GPU sustains
         achieved_local = alg_bytes * args.steps * lps / elapsed_local / 1e9
@@ -472,7 +482,7 @@ def _main():
             idx = np.linspace(0, n - 1, min(per, n)).astype(np.int64)
             tidx = torch.from_numpy(idx).to(dev)
             fr = d_batches[b if ns == 1 else last_b0][tidx].cpu().numpy()
-            want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
+            want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget if not cycle else np.array([cycle[(first + int(i)) % len(cycle)] for i in idx], np.int32), stride=budget)
             got = d_outs[b if ns == 1 else 0][tidx].cpu().numpy()[:, :budget]
             ok = ok and bool(rc == 0 and np.array_equal(got, want) and np.array_equal(r[idx], want_res))
             checked += int(idx.size)
@@ -491,7 +501,7 @@ def _main():
                 secondary.update(_secondary_configs(args))
 
     version = _lib.lib().psxhip_version().decode()
-    wl_key = "sbs codec=%d %dx%d budget=%d frames=%d amp=%d | %s" % (args.codec, w, h, budget, n, args.amp, version)
+    wl_key = "sbs codec=%d %dx%d budget=%s frames=%d amp=%d | %s" % (args.codec, w, h, ("%d" % budget) if not cycle else "cycle(" + args.budget_cycle + ")", n, args.amp, version)
     traffic, traffic_src, pmc = _profile_traffic(wl_key)
     # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds its SIMD's issue slot for 4 cycles;
     # instructions per launch come from the same committed PMC pass as the traffic (SQ_INSTS_VALU).
@@ -533,7 +543,7 @@ def _main():
                                       lps, nb, budget, args.amp),
                        "preset": args.config, "baseline_config": args.baseline_config,
                        "frames_per_gpu_per_launch": n, "launches_per_step": lps, "distinct_batches": nb, "width": w, "height": h,
-                       "frame_max_size": budget,
+                       "frame_max_size": budget, "budget_cycle": cycle,
                        "parallelism": "frames sharded x%d (contiguous ranges per rank), no data-path collective" % world,
                        "kernel_shape": {"groups_per_cu": geo.groups_per_cu, "wavefronts_per_group": geo.wavefronts_per_group,
                                         "image_tile_bytes": geo.image_tile_bytes, "frames_in_flight": geo.frames_in_flight},

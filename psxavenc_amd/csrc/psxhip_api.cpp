@@ -559,10 +559,15 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
     }
     if (n_frames == 0) return PSXHIP_OK;
     HIP_TRY(hipSetDevice(c->device), PSXHIP_EDEVICE);
-    // the host path uses both launch lanes on its own streams: launches the caller left outstanding on them (two lanes, no fence
-    // yet) are waited for first -- a lane's launches must be ordered
+    // the host path uses both launch lanes on its own streams: whatever the caller's device-path launches left running on the
+    // lanes' streams is waited for first -- a lane's launches must be ordered.  (lane_pending says "no caller stream has been
+    // ordered behind this launch yet", not "still running": after psxhip_mdec_fence, or after the next device call took the
+    // dependency over, the launch may still be in flight with the flag down -- so every lane stream that exists is drained.)
     for (int l = 0; l < kLanes; l++)
-        if (c->lane_pending[l]) HIP_TRY(hipStreamSynchronize(c->lane_stream[l]), PSXHIP_EDEVICE);
+        if (c->lane_stream[l]) {
+            HIP_TRY(hipStreamSynchronize(c->lane_stream[l]), PSXHIP_EDEVICE);
+            c->lane_pending[l] = false;
+        }
     const size_t fsz = (size_t)c->width * c->height * 3 / 2;
     int max_size = uniform_max_size;
     if (frame_max_sizes) {

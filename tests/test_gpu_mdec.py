@@ -770,3 +770,49 @@ def test_host_path_after_unfenced_lane_launches(torch_cuda):
             assert np.array_equal(r.cpu().numpy(), want_r) and np.array_equal(o.cpu().numpy(), want_o)
     assert enc.watchdog() == 0
     enc.close()
+
+
+def test_host_path_after_fenced_but_still_running_lane_launches(torch_cuda):
+    """psxhip_mdec_fence clears a lane's "pending" flag while the launch may still be running -- the flag means
+    "nobody ordered behind it yet", not "in flight".  Sequence: two lanes; device launches of a LARGE batch (long enough to be
+    in flight when the host call arrives); fence; then, with no stream synchronise, the host-buffer entry points of the same
+    context (they use both lanes' ticket counters on their own streams).  Also: two device calls, then a host call (lane 0's flag
+    was cleared by the second call).  Every byte as with one lane."""
+    torch = torch_cuda
+    w, h, budget, n = 320, 240, 8192, 4000
+    frames = O.synth_frames(w, h, 400, seed=78, amp=8)
+    big = np.concatenate([frames] * (n // 400), axis=0)
+    d_frames = torch.from_numpy(big).to("cuda:0")
+    one = encoder(0, w, h, budget)
+    want_o, want_r = one.encode_frames_device(d_frames[:400], budget)
+    torch.cuda.synchronize()
+    want_o, want_r = want_o.cpu().numpy(), want_r.cpu().numpy()
+    one.close()
+    enc = encoder(0, w, h, budget)
+    enc.set_lanes(2)
+    d_out = [torch.zeros((n, budget), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    d_res = [torch.zeros((n, 4), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    for rep in range(6):
+        for k in range(2):
+            d_res[k].zero_()
+        enc.encode_frames_device(d_frames, budget, d_out=d_out[0], d_results=d_res[0])
+        if rep % 3 != 2:
+            enc.encode_frames_device(d_frames, budget, d_out=d_out[1], d_results=d_res[1])
+        if rep % 3 == 0:
+            enc.fence()                      # flags down, launches still running
+        if rep & 1:
+            ho, hr = enc.encode_frames_host(frames[:300], budget)
+            assert np.array_equal(hr, want_r[:300]) and np.array_equal(ho, want_o[:300, :budget])
+        else:
+            enc.frame_max_size = budget
+            bs = enc.encode_frame_bs(frames[7])
+            assert np.array_equal(bs, want_o[7, :budget]) and enc.quant_scale == want_r[7, 0]
+        enc.fence()
+        torch.cuda.synchronize()
+        for k in range(2 if rep % 3 != 2 else 1):
+            r = d_res[k].cpu().numpy().reshape(n // 400, 400, 4)
+            o = d_out[k].cpu().numpy().reshape(n // 400, 400, budget)
+            for j in range(n // 400):
+                assert np.array_equal(r[j], want_r) and np.array_equal(o[j], want_o), (rep, k, j)
+    assert enc.watchdog() == 0
+    enc.close()
