@@ -101,7 +101,10 @@ int psxhip_mdec_encode_batches_device(psxhip_mdec_ctx_t *ctx, const psxhip_mdec_
  *     input or output buffers) must have called one of the two first -- i.e. it double-buffers, which is what lets the head of
  *     launch k+1 fill the tail of launch k.
  * Bytes never depend on the number of lanes.  lanes: 1 or 2.  Switching waits for the context's outstanding launches, and so do
- * the host-buffer entry points of the same context (psxhip_mdec_encode_frames_host*, encode_frame_bs): they use both lanes. */
+ * the host-buffer entry points of the same context (psxhip_mdec_encode_frames_host*, encode_frame_bs): they use both lanes, on the
+ * context's own streams.  With ONE lane a device-path launch runs on the caller's stream with lane 0's hand-out counters and nothing
+ * orders a later host-buffer call (encode_frame_bs included) behind it: a caller that mixes the two on one context synchronises
+ * its stream first -- the rule above (launches on one context are stream-ordered) applies to the host entry points too. */
 int psxhip_mdec_set_lanes(psxhip_mdec_ctx_t *ctx, int lanes);
 /* order `stream` behind every launch of the context issued so far (a no-op with one lane) */
 int psxhip_mdec_fence(psxhip_mdec_ctx_t *ctx, void *stream);
@@ -224,6 +227,12 @@ int psxhip_adpcm_session_create(psxhip_adpcm_session_t **session, int device, co
 int psxhip_adpcm_session_run(psxhip_adpcm_session_t *session, const psxhip_adpcm_state_t *start_states,
                              const uint8_t *start_known, int max_passes, psxhip_adpcm_state_t *final_states,
                              int *any_change);
+/* Measurement: HIP events around the speculate launch and around the verify passes of every run that speculates (the first run
+ * after create / reset); _last_timing returns the last such run's two durations in milliseconds.  Off by default. */
+int psxhip_adpcm_session_set_timing(psxhip_adpcm_session_t *session, int on);
+int psxhip_adpcm_session_last_timing(const psxhip_adpcm_session_t *session, float *speculate_ms, float *verify_ms);
+/* revision of the ADPCM kernels (profiles/pmc_index.json is keyed by it, like the frame kernel's in psxhip_version()) */
+const char *psxhip_adpcm_kernel_rev(void);
 /* forget the speculative encode: the next psxhip_adpcm_session_run starts over (the samples may have changed) */
 void psxhip_adpcm_session_reset(psxhip_adpcm_session_t *session);
 void psxhip_adpcm_session_destroy(psxhip_adpcm_session_t *session);

@@ -12,6 +12,12 @@
  *       37800 Hz 4-bit stereo XACD sectors: the reference's own psx_audio_xa_encode when the path of oracle/_ref's
  *       library is given (libpsxav/adpcm.c compiled unchanged), else oracle/adpcm_oracle.c.  Every thread encodes its own
  *       40 sectors of kind-0 PCM, state carried, round-robin.
+ *   cpu_bench str <threads> <seconds> <seed> [ref.so]
+ *       config 3 (`strcd v2`): the sector loop of encode_file_str (psxavenc/filefmt.c:450-503) in C -- 320x240 @15 fps BS v2 through
+ *       orc_mdec_encode_sector_str (the restatement of mdec.c:757-836), one 37800 Hz 4-bit stereo XA sector in eight (the
+ *       reference's own psx_audio_xa_encode when ref.so is given), mode-2 form-1 headers and EDC around the video sectors.  Every
+ *       thread muxes its own 24 frames + their audio over and over.  (bench.py timed this loop in Python until round 5; the
+ *       interpreter was in the number.)
  * Prints one JSON object: units (frames / sectors) per second over all threads, and per thread min / max.
  */
 #define _GNU_SOURCE
@@ -72,6 +78,59 @@ static void *work(void *p) {
 		j->units = n;
 		free(frames);
 		free(out);
+	} else if (j->mode == 2) {
+		enum { W = 320, H = 240, NF = 24, SPS = 2016, INTERLEAVE = 8 };
+		const size_t fsz = (size_t)W * H * 3 / 2;
+		const int n_audio = NF * 10 / INTERLEAVE + 2, total = SPS * n_audio;
+		uint8_t *frames = malloc(fsz * NF);
+		for (int i = 0; i < NF; i++) orc_synth_frame(W, H, j->seed, (uint32_t)(j->index * NF + i), 4, frames + fsz * i);
+		int16_t *pcm = calloc((size_t)(total + 4032) * 2, sizeof(int16_t));
+		int16_t *tmp = malloc((size_t)total * sizeof(int16_t));
+		for (int c = 0; c < 2; c++) {
+			orc_synth_pcm(j->seed, (uint32_t)(2 * j->index + c), 0, total, 0, tmp);
+			for (int i = 0; i < total; i++) pcm[2 * i + c] = tmp[i];
+		}
+		free(tmp);
+		uint8_t frame_output[2016 * 10];
+		orc_xa_settings_t os = {1, 1, 37800, 4, 1, 0};
+		ref_xa_settings_t rs = {1, true, 37800, 4, 1, 0};
+		pthread_barrier_wait(j->start);
+		const double t0 = now();
+		long n = 0;
+		do {
+			/* one little stream: filefmt.c:422-443 (state), then the sector loop until the frames are used up */
+			orc_adpcm_state_t ost;
+			ref_state_t rst;
+			memset(&ost, 0, sizeof ost);
+			memset(&rst, 0, sizeof rst);
+			orc_str_state_t st;
+			memset(&st, 0, sizeof st);
+			st.base_overflow = 75 * 2 * (INTERLEAVE - 1) * 1;
+			st.overflow_den = INTERLEAVE * 15;
+			st.frame_output = frame_output;
+			int frame = 0, audio = 0;
+			for (int sector_count = 0; frame < NF - 2 || st.frame_data_offset < st.frame_max_size; sector_count++) {
+				uint8_t sector[2352];
+				memset(sector, 0, sizeof sector);
+				if (sector_count % INTERLEAVE) {
+					orc_cdrom_init_sector(sector, sector_count, 1);
+					sector[16] = 1; sector[17] = 0; sector[18] = 0x08 | 0x40; sector[19] = 0;
+					memcpy(sector + 20, sector + 16, 4);
+					frame += orc_mdec_encode_sector_str(&st, 0, W, H, ORC_FMT_STRCD, 0x8001, frames + fsz * (frame < NF ? frame : NF - 1), sector);
+					orc_cdrom_calculate_checksums(sector, 1);
+				} else {
+					const int16_t *src = pcm + (size_t)(audio < n_audio ? audio : n_audio - 1) * SPS * 2;
+					const int len = j->ref_xa ? j->ref_xa(rs, &rst, src, SPS, sector_count, sector) : orc_xa_encode(os, &ost, src, SPS, sector_count, sector);
+					if (len != 2352) j->failed = 1;
+					audio++;
+				}
+				n++;
+			}
+		} while (now() - t0 < j->seconds);
+		j->elapsed = now() - t0;
+		j->units = n;
+		free(frames);
+		free(pcm);
 	} else {
 		const int sps = 2016, total = sps * SECTORS_PER_THREAD;
 		int16_t *pcm = calloc((size_t)(total + 4032) * 2, sizeof(int16_t));
@@ -104,13 +163,64 @@ static void *work(void *p) {
 	return NULL;
 }
 
+/* cpu_bench converge <kind> <warmup units> <seed: 0 silence, 1 raw history> <starts> <cap units> <filters> <range>
+ * How far a wrong start state travels (what bounds the GPU's speculate-and-verify): the serial encode of a
+ * long chain of synthetic PCM gives the true state after every unit; from `starts` evenly spaced units an encoder is started
+ * `warmup` units early -- from silence, or from the two RAW samples in front of it -- and the units from the start on are counted
+ * until its state equals the true one (cap = never within that many).  Prints the distribution as JSON. */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+static int converge_main(int argc, char **argv) {
+	if (argc < 9) return 2;
+	const int kind = atoi(argv[2]), warm = atoi(argv[3]), seed_raw = atoi(argv[4]), starts = atoi(argv[5]), cap = atoi(argv[6]);
+	const int filters = atoi(argv[7]), range = atoi(argv[8]);
+	const int spacing = 2000, n_units = (starts + 2) * spacing + cap + warm + 8;
+	int16_t *pcm = malloc((size_t)n_units * 28 * sizeof(int16_t));
+	orc_synth_pcm(5, 3, 0, n_units * 28, kind, pcm);
+	orc_adpcm_chan_t *truth = malloc((size_t)n_units * sizeof(orc_adpcm_chan_t));
+	orc_adpcm_chan_t st = {0, 0};
+	uint8_t codes[28];
+	for (int u = 0; u < n_units; u++) {
+		(void)orc_adpcm_encode_unit(&st, pcm + (size_t)u * 28, 28, 1, filters, range, codes);
+		truth[u] = st;
+	}
+	int *dist = malloc((size_t)starts * sizeof(int));
+	long sum = 0;
+	int never = 0, at_start = 0;
+	for (int k = 0; k < starts; k++) {
+		const int first = (k + 1) * spacing;
+		orc_adpcm_chan_t g = {0, 0};
+		const int w0 = first - warm;
+		if (seed_raw) { g.prev1 = pcm[(size_t)w0 * 28 - 1]; g.prev2 = pcm[(size_t)w0 * 28 - 2]; }
+		for (int u = w0; u < first; u++) (void)orc_adpcm_encode_unit(&g, pcm + (size_t)u * 28, 28, 1, filters, range, codes);
+		int d = 0;
+		if (g.prev1 == truth[first - 1].prev1 && g.prev2 == truth[first - 1].prev2) at_start++;
+		else {
+			for (d = 1; d <= cap; d++) {
+				(void)orc_adpcm_encode_unit(&g, pcm + (size_t)(first + d - 1) * 28, 28, 1, filters, range, codes);
+				if (g.prev1 == truth[first + d - 1].prev1 && g.prev2 == truth[first + d - 1].prev2) break;
+			}
+			if (d > cap) never++;
+		}
+		dist[k] = d;
+		sum += d > cap ? cap : d;
+	}
+	qsort(dist, (size_t)starts, sizeof(int), cmp_int);
+	printf("{\"mode\": \"converge\", \"kind\": %d, \"warmup_units\": %d, \"seed\": \"%s\", \"starts\": %d, \"cap\": %d, \"guess_was_the_truth\": %d, "
+	       "\"mean_units\": %.2f, \"median\": %d, \"p90\": %d, \"max\": %d, \"never_within_cap\": %d}\n",
+	       kind, warm, seed_raw ? "raw history" : "silence", starts, cap, at_start, (double)sum / starts, dist[starts / 2], dist[starts * 9 / 10], dist[starts - 1], never);
+	free(pcm); free(truth); free(dist);
+	return 0;
+}
+
 int main(int argc, char **argv) {
+	if (argc >= 2 && strcmp(argv[1], "converge") == 0) return converge_main(argc, argv);
 	if (argc < 5) {
 		fprintf(stderr, "usage: cpu_bench mdec <threads> <seconds> <codec> <w> <h> <budget> <amp> <seed>\n"
-		                "       cpu_bench xa <threads> <seconds> <seed> [path to oracle/_ref/libpsxav_ref.so]\n");
+		                "       cpu_bench xa <threads> <seconds> <seed> [path to oracle/_ref/libpsxav_ref.so]\n"
+		                "       cpu_bench str <threads> <seconds> <seed> [path to oracle/_ref/libpsxav_ref.so]\n");
 		return 2;
 	}
-	const int mode = strcmp(argv[1], "xa") == 0;
+	const int mode = strcmp(argv[1], "xa") == 0 ? 1 : (strcmp(argv[1], "str") == 0 ? 2 : 0);
 	const int threads = atoi(argv[2]);
 	const double seconds = atof(argv[3]);
 	if (threads < 1 || threads > 4096 || seconds <= 0) return 2;
@@ -128,7 +238,7 @@ int main(int argc, char **argv) {
 		if (argc > 5) {
 			void *h = dlopen(argv[5], RTLD_NOW | RTLD_LOCAL);
 			if (h) proto.ref_xa = (ref_xa_encode_fn)dlsym(h, "psx_audio_xa_encode");
-			if (proto.ref_xa) kind = "reference";
+			if (proto.ref_xa && mode == 1) kind = "reference";      /* (str: the video leg is the port whatever encodes the audio) */
 		}
 	}
 	(void)orc_mdec_ac_code(0, 1);        /* build the oracle's lazily built VLC tables before the threads start */
@@ -157,6 +267,6 @@ int main(int argc, char **argv) {
 	}
 	printf("{\"mode\": \"%s\", \"kind\": \"%s\", \"threads\": %d, \"units\": %ld, \"seconds\": %.3f, \"units_per_sec\": %.2f, "
 	       "\"per_thread_min\": %.2f, \"per_thread_max\": %.2f, \"failed\": %d}\n",
-	       mode ? "xa" : "mdec", kind, threads, total, longest, rate, lo, hi, failed);
+	       mode == 1 ? "xa" : (mode == 2 ? "str" : "mdec"), kind, threads, total, longest, rate, lo, hi, failed);
 	return failed ? 1 : 0;
 }

@@ -318,6 +318,18 @@ class AdpcmSession:
         self.passes += rc
         return final, bool(changed.value)
 
+    def set_timing(self, on=True):
+        """HIP events around the speculate launch and the verify passes of the runs that speculate (psxhip_adpcm_session_set_timing)"""
+        self._L.psxhip_adpcm_session_set_timing.argtypes = [C.c_void_p, C.c_int]
+        _lib.check(self._L.psxhip_adpcm_session_set_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        """(speculate_ms, verify_ms) of the last run that speculated with timing on"""
+        a, b = C.c_float(0), C.c_float(0)
+        self._L.psxhip_adpcm_session_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.check(self._L.psxhip_adpcm_session_last_timing(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def reset(self):
         """forget the speculative encode: the next run() starts over on the same buffers"""
         self._L.psxhip_adpcm_session_reset.argtypes = [C.c_void_p]

@@ -67,6 +67,13 @@ constexpr uint32_t kRetryEmpty = 0xFFFFFFFFu, kRetryAbandoned = 0xFFFFFFFEu;
 // arithmetic on the returned value -- anything computed from it on the spot would make the compiler wait for the atomic there.)
 constexpr int kQueueWord = 64;
 constexpr int kStartedWord = 96;         // groups of this launch that have started (a cache line of its own; self-resetting)
+// Groups that have left | abandoned queue slots << 16 | what the groups learned about foreign hints: wrong << 32 | tried << 48 (each
+// group adds at most kTrustCap of either) -- ONE 64-bit word, so that the group that leaves last sees every other group's sums
+// without a fence: they were added by the same atomic that counted the group out.
+constexpr int kLeaveWord = 8;
+constexpr int kLeaveWrongShift = 32, kLeaveTriedShift = 48;
+constexpr unsigned kTrustCap = 63u;
+constexpr int kDistrustWord = 4;         // hint[kDistrustWord]: the launches before this one found foreign hints wrong more than one time in four (shared by the context's lanes, like the hint)
 constexpr int kQueueReservedShift = 32, kQueueHeadShift = 48;
 constexpr unsigned kQueueMask = 0xFFFFu;
 // A look at a word other XCDs write: a device-scope load (it bypasses this XCD's L2); after many looks in vain, a read-modify-write
@@ -99,6 +106,7 @@ struct FrameJob {
     size_t frame_stride;
     int width, height, nx, ny, nmb;
     int n_frames;                  // over all batches
+    int n_tickets, t4, t2;         // frame tickets of the launch: the first t4 are runs of 4 consecutive frames, the next t2 runs of 2, the rest single frames (ticket_run())
     int uniform_max_size;
     size_t out_stride;
     int out_words;           // LDS dwords reserved for the frame image tile (out_tile + 2)
@@ -139,12 +147,24 @@ __device__ __forceinline__ unsigned int* retry_slots(const FrameJob& job) {
 __device__ __forceinline__ unsigned long long* queue_state(const FrameJob& job) { return (unsigned long long*)&job.ticket[kQueueWord]; }
 // the next fresh-frame ticket: the low half of the state word (what the waiting groups look at)
 __device__ __forceinline__ unsigned draw_ticket(const FrameJob& job) { return (unsigned)atomicAdd(queue_state(job), 1ull); }
+__device__ __forceinline__ unsigned long long* leave_word(const FrameJob& job) { return (unsigned long long*)&job.ticket[kLeaveWord]; }
+// Frame ticket t -> its run of consecutive frames.  Runs are what gives a frame a hint worth trusting: inside a run a group encodes
+// neighbours in time one after the other, and the answer of frame f - 1 is the best predictor of frame f there is (decoded video:
+// scenes of similar frames).  With single-frame tickets handed out in index order a group's previous frame lies a whole round of the
+// grid back -- 512 frames: another scene.  Long runs first, short ones at the end (the host sizes t4 / t2 so that every round of
+// the grid is whole, psxhip_mdec_launch): guided self-scheduling, the tail of a launch is still balanced frame by frame.
+__device__ __forceinline__ void ticket_run(const FrameJob& job, int t, int& first, int& len) {
+    const int t4 = job.t4, t42 = job.t4 + job.t2;
+    if (t < t4) { first = 4 * t; len = 4; }
+    else if (t < t42) { first = 4 * t4 + 2 * (t - t4); len = 2; }
+    else { first = 4 * t4 + 2 * job.t2 + (t - t42); len = 1; }
+}
 
-// scalars[] slots (LDS, per workgroup)
+// scalars[] slots (LDS, per workgroup).  [0, S_KEEP0) are per-frame: cleared when a frame ends; [S_KEEP0, S_COUNT) live across frames.
 enum {
     S_DC_BITS = 0,      // v3: sum of the DC code lengths
     S_STG_NEXT,         // staging bump allocator (dwords)
-    S_OVERFLOW,         // (unused)
+    S_FOREIGN,          // the hint this frame started with came from somewhere else than its neighbour in time (the group's previous run, the previous launch): its value, 0 if none -- what the trust policy learns from when the answer is known
     S_CNT_F,            // count pass: sum of AC code lengths
     S_CNT_D,            // count pass: sum of refinement deficits
     S_EMIT_BITS,        // emit pass: sum of macroblock stream lengths
@@ -155,33 +175,40 @@ enum {
     S_DONE,             // search finished
     S_RESULT,           // chosen scale (64 = nothing fits)
     S_TOTAL_BITS,       // bits of the staged stream incl. the end-of-frame code
-    S_FRAME,            // ticket
     S_PILOT_N,          // scales in this pilot round (0 = pilot finished)
     S_PILOT_GUESS,
     S_PILOT_LO,
     S_PILOT_HI,
     S_CK_DONE,          // checkpoint: macroblocks finished so far in this pass
     S_MB_NEXT,          // pass tickets: next macroblock ticket to hand out
-    S_CK_SQ,            // (unused)
-    S_CK_S1,            // (unused)
     S_CK_WAVES,         // checkpoint: wavefronts whose sums up to the quarter mark are in
     S_ABORT,            // checkpoint verdict: new guess | pass number << 8 (a verdict of an earlier pass is stale, not reset)
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_RETRY,            // this frame came from the retry queue: the scale to start from (0: a fresh frame; -1: the queue is empty)
     S_DEFER,            // the frame goes to the retry queue instead of into another pass here
-    S_PUSHED,           // the previous fresh frame of this group was handed on (see hand_on: whose hint the next frame starts from)
-    S_QUEUE,            // drawn with the last frame's end when no fresh ticket is left: >= 0 the queue slot to take, -1 nothing will come, <= -2 wait for slot -2 - x
-    S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
-    S_HINT_BUDGET,      // ... and its budget
-    S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
-    S_NEXT_DRAW,        // thread 0's ticket for the frame after next, parked here over the passes (it is a register from the draw to the start of the next frame's passes: the atomic's round trip hides behind a frame's work, and the passes have no register to spare)
-    S_PAD0,
+    S_PILOTED,          // the pilot has run for this frame (its guess is a measurement, not somebody else's answer)
+    S_REPILOT,          // the first pass, started from a hint, was stopped with a verdict FAR from the hint (a scene cut): the verdict; the frame starts over from the pilot
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
     S_TILE_FIRST0 = S_PILOT_BITS0 + kPilotMax,    // [kMaxTiles + 1] first macroblock whose stream starts in image tile t (see the merge)
-    S_COUNT = S_TILE_FIRST0 + kMaxTiles + 1
+    S_KEEP0 = S_TILE_FIRST0 + kMaxTiles + 1,
+    S_FRAME = S_KEEP0,  // the frame TICKET in hand (a ticket is a run of 1, 2 or 4 consecutive frames: ticket_run())
+    S_FIDX,             // index of the frame being encoded (inside the ticket's run, or a frame taken from the retry queue)
+    S_RUN_LEFT,         // frames of the ticket's run behind the one being encoded
+    S_PUSHED,           // the previous fresh frame of this group was handed on (see hand_on: whose hint the next frame starts from)
+    S_QUEUE,            // drawn with the last frame's end when no fresh ticket is left: >= 0 the queue slot to take, -1 nothing will come, <= -2 wait for slot -2 - x
+    S_HINT,             // the previous frame's answer in this group (0 = none): the pilot starts from it
+    S_HINT_BUDGET,      // ... and its budget
+    S_HINT_FRAME,       // ... and its index: the hint is the neighbour's answer when that is this frame's index - 1 (inside a run), foreign otherwise
+    S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
+    S_NEXT_DRAW,        // thread 0's ticket for the run after this one, parked here over the passes (it is a register from the draw to the start of the next frame's passes: the atomic's round trip hides behind a frame's work, and the passes have no register to spare)
+    S_DISTRUST,         // foreign hints are not trusted: frames without a neighbour's answer run the pilot (trust policy, below)
+    S_F_TRIED,          // foreign hints this group could judge (the frame's answer became known here)
+    S_F_WRONG,          // ... and how many of them were not the answer
+    S_COUNT
 };
+static_assert((S_SEARCH % 2) == 0, "MdecSearch is read and written as 64-bit pairs");
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -746,7 +773,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
     const uint8_t pro_plen = c_dc_plen[(tid >> 3) & 1][tid & 7], pro_prefix = c_dc_prefix[(tid >> 3) & 1][tid & 7];
     const uint8_t pro_qzz = c_quant_zz[tid & 63], pro_zagzig = c_zagzig[tid & 63];
-    const unsigned pro_shared_hint = *job.hint;
+    const unsigned pro_shared_hint = *job.hint, pro_distrust = job.hint[kDistrustWord];
 #pragma unroll
     for (int j = 0; j < kLutTrips; j++) {
         const int i = tid + j * kThreads;
@@ -783,7 +810,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const unsigned hw_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) ;   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
     const unsigned prio_bits = (WAVES == kWavesSmall && hw_slot >= (unsigned)(kWavesSmall / 4)) ? (job.prio_pattern >> 8) & 0xFFu : job.prio_pattern & 0xFFu;
     const unsigned prio_bits4 = prio_bits * 0x01010101u;      // the pattern four times over: bit (iteration & 31) is bit (iteration & 7)
-    if (tid == 0) { L.scalars[S_HINT] = 0; L.scalars[S_SHARED_HINT] = (int)pro_shared_hint; }
+    if (tid == 0) {
+        L.scalars[S_HINT] = 0; L.scalars[S_HINT_BUDGET] = 0; L.scalars[S_HINT_FRAME] = -2; L.scalars[S_SHARED_HINT] = (int)pro_shared_hint;
+        L.scalars[S_DISTRUST] = (int)pro_distrust; L.scalars[S_F_TRIED] = 0; L.scalars[S_F_WRONG] = 0;
+        L.scalars[S_PUSHED] = 0; L.scalars[S_QUEUE] = 0; L.scalars[S_NEXT_DRAW] = 0;
+    }
     unsigned pass_sum = 0, pass_hist[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_start = 0, t_mark = 0, phase_ticks[6] = {0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {       // diagnostics: time since the previous mark goes to `phase`
@@ -837,7 +868,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // from it before the next frame's decisions, so the atomic's round trip hides behind a frame's work (adding gridDim.x -- a
     // scalar load -- on the spot made the compiler wait for the atomic right there, at every frame's end)
     unsigned next_draw = 0;
-    const unsigned fresh_draws = (unsigned)job.n_frames - gridDim.x;      // draws below this are real frames (grid <= n_frames)
+    // draws below this are real tickets (the first gridDim.x tickets are the groups' own; a launch may have more groups than tickets --
+    // the surplus only ever takes frames from the retry queue)
+    const unsigned fresh_draws = (unsigned)job.n_tickets > gridDim.x ? (unsigned)job.n_tickets - gridDim.x : 0u;
     // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
     // hands out the frames after those
     if (tid == 0) {
@@ -850,32 +883,66 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         unsigned f0 = blockIdx.x;
         if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
         L.scalars[S_FRAME] = (int)f0;
-        next_draw = draw_ticket(job);
+        // A group draws the ticket for its NEXT run when it enters the LAST frame of the run in hand -- one frame ahead of the
+        // need, and not before: "this group holds a further fresh frame" (what allows it to hand a frame on, hand_on) is then
+        // "frames left in the run, or the ticket in hand is a real one", and the draw that comes up blank still marks the moment
+        // the group enters its last fresh frame, which is what the retry queue's protocol counts on.
+        int first = 0, len = 1;
+        if ((int)f0 < job.n_tickets) ticket_run(job, (int)f0, first, len);
+        L.scalars[S_FIDX] = first;
+        L.scalars[S_RUN_LEFT] = len - 1;
+        if ((int)f0 >= job.n_tickets) {
+            // more groups than tickets (a launch of at most one run per group whose frames may be handed on): this group only ever
+            // takes frames from the queue; it draws its place there right away
+            if (job.retry) {
+                const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
+                const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
+                L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_tickets ? -1 : -2 - (int)h;
+            }
+        } else if (len == 1) {
+            next_draw = draw_ticket(job);
+        }
         if (job.retry) atomicAdd(&job.ticket[kStartedWord], 1u);      // (nobody waits for a frame to be handed on before all groups are here)
     }
     // Per-frame state (frame image tile, staging area, scalars) is cleared, and the next ticket published, while a frame's
     // last tile is written out: the barrier that ends a frame is also the one that starts the next.
     auto end_of_frame = [&](int tid, bool parked = true) {
         for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-        if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_HINT_BUDGET && tid != S_SHARED_HINT && tid != S_QUEUE && tid != S_PUSHED && tid != S_NEXT_DRAW) L.scalars[tid] = 0;
+        if (tid < S_KEEP0) L.scalars[tid] = 0;
         if (tid == 0) {
-            // tickets hand frames out in order, so workgroups that draw cheap frames simply draw more
+            // tickets hand runs out in order, so workgroups that draw cheap frames simply draw more
             if (parked) next_draw = (unsigned)L.scalars[S_NEXT_DRAW];
-            L.scalars[S_FRAME] = (int)(next_draw + gridDim.x);
-            if (next_draw < fresh_draws) {
-                next_draw = draw_ticket(job);
-            } else if (job.retry) {
-                // no fresh frame left for this group: in place of the ticket it draws its place in the retry queue (see the top of
-                // the frame loop), in the shadow of the same write-out
-                const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
-                const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
-                L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_frames ? -1 : -2 - (int)h;
+            const int left = L.scalars[S_RUN_LEFT];
+            bool entered_last;                 // the frame this group moves to is the last of its run
+            if (left > 0 && L.scalars[S_FRAME] < job.n_tickets) {
+                L.scalars[S_RUN_LEFT] = left - 1;
+                L.scalars[S_FIDX] = L.scalars[S_FIDX] + 1;
+                entered_last = left == 1;
+            } else {
+                const int t = L.scalars[S_FRAME] < job.n_tickets ? (int)(next_draw + gridDim.x) : in_loop(0x7FFFFFFF);    // (a group that only takes frames from the queue holds no ticket)
+                L.scalars[S_FRAME] = t;
+                entered_last = false;
+                if (t < job.n_tickets) {
+                    int first, len;
+                    ticket_run(job, t, first, len);
+                    L.scalars[S_FIDX] = first;
+                    L.scalars[S_RUN_LEFT] = len - 1;
+                    entered_last = len == 1;
+                } else if (job.retry) {
+                    // no fresh frame left for this group: in place of the ticket it draws its place in the retry queue (see the top of
+                    // the frame loop), in the shadow of the same write-out
+                    L.scalars[S_RUN_LEFT] = 0;
+                    const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
+                    const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
+                    L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_tickets ? -1 : -2 - (int)h;
+                }
             }
+            if (entered_last) next_draw = draw_ticket(job);
         }
     };
     for (int i = tid; i < job.out_tile + 1; i += kThreads) L.out[i] = 0u;
     for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
-    if (tid < S_COUNT && tid != S_FRAME && tid != S_HINT && tid != S_SHARED_HINT) L.scalars[tid] = 0;
+    if (tid < S_KEEP0) L.scalars[tid] = 0;
     __syncthreads();
     for (;;) {
         // thread- and lane-derived values (loop bases, masks, LDS addresses, even the predicate "thread 0") are re-derived per
@@ -884,8 +951,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         int tid_f = (int)threadIdx.x;
         asm volatile("" : "+v"(tid_f));
         const int tid = tid_f;               // shadows the kernel-scope copy on purpose
-        int f = L.scalars[S_FRAME];
-        if (f >= job.n_frames) {
+        int f = L.scalars[S_FIDX];
+        if (L.scalars[S_FRAME] >= job.n_tickets) {
             // No fresh frame left for this group: frames that other groups handed on instead of running another pass over them
             // (see the end of the pass loop).  Everything here goes through read-modify-write atomics -- the queue is shared by
             // groups on all XCDs, whose L2s are not coherent for plain loads.  A group leaves when it finds the queue empty;
@@ -911,12 +978,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     const unsigned long long w = queue_peek(queue_state(job), looks);
                     const unsigned started = queue_peek(&job.ticket[kStartedWord], looks);
                     if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
-                    if ((unsigned)w >= (unsigned)job.n_frames) break;
+                    if ((unsigned)w >= (unsigned)job.n_tickets) break;
                     // a group that has not started may be waiting for THIS group's place on a CU: then nobody waits
                     if (started < gridDim.x || looks >= job.retry_patience) {
                         if (h < (unsigned)job.retry_cap) {
                             if (atomicCAS(&retry_slots(job)[h], (unsigned)in_loop((int)kRetryEmpty), (unsigned)in_loop((int)kRetryAbandoned)) != kRetryEmpty) there = true;      // filled this very moment
-                            else atomicAdd(&job.ticket[1], 0x10000u);          // a note for the group that re-arms the queue
+                            else atomicAdd(leave_word(job), 0x10000ull);          // a note for the group that re-arms the queue
                         }
                         break;
                     }
@@ -936,10 +1003,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                     if (v == kRetryEmpty) {
                         v = atomicCAS(&retry_slots(job)[h], (unsigned)in_loop((int)kRetryEmpty), (unsigned)in_loop((int)kRetryAbandoned));
-                        if (v == kRetryEmpty) { atomicAdd(&job.ticket[3], 1u); atomicAdd(&job.ticket[1], 0x10000u); }
+                        if (v == kRetryEmpty) { atomicAdd(&job.ticket[3], 1u); atomicAdd(leave_word(job), 0x10000ull); }
                     }
                     if (v != kRetryEmpty) {
-                        L.scalars[S_FRAME] = (int)(v & 0xFFFFFFu);
+                        L.scalars[S_FIDX] = (int)(v & 0xFFFFFFu);
                         got = (int)(v >> 24);
                         retry_slots(job)[h] = (unsigned)in_loop((int)kRetryEmpty);          // vacated for the next launch (nobody looks at it again in this one)
                     }
@@ -948,7 +1015,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
             __syncthreads();
             if (L.scalars[S_RETRY] < 0) break;
-            f = L.scalars[S_FRAME];
+            f = L.scalars[S_FIDX];
         }
 
         const int lane = tid & 63;
@@ -1255,8 +1322,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // (consecutive tickets are neighbouring frames); the quarter-pass checkpoint catches the cases where it is off.
         // A group's first frame borrows the answer of the previous launch's last frame (the tail of the previous batch --
         // temporally adjacent when batches follow each other in a stream).
+        // Trust policy.  A hint is LOCAL when it is the answer of this frame's neighbour in time (the frame before it in the group's
+        // run): trusted, the quarter-pass checkpoint catches the scene cuts.  Every other hint is FOREIGN -- the last frame of the
+        // group's previous run, a whole round of the grid away, or the previous launch's last answer: right on content that does not
+        // change (the uniform synthetic batches), wrong three times in four on scene-structured video (tools/gpu_r05_diag.py: 2.3
+        // passes per frame).  Foreign hints are trusted until they have been wrong: a group that trusted one in vain runs the
+        // pilot on its following run starts (the foreign hint then only tells the pilot where to look first), and goes back to trusting
+        // when a foreign hint would have been right; every group reports what it saw when it leaves, and the launch's verdict
+        // (more than one in four wrong) is where the next launch's groups start from (hint[kDistrustWord]).
         int hint = L.scalars[S_HINT];
         int hint_budget = L.scalars[S_HINT_BUDGET];
+        bool local = hint >= 1 && L.scalars[S_HINT_FRAME] == f - 1;
         if (hint < 1) {
             const int sh = L.scalars[S_SHARED_HINT];
             hint = sh & 0xFF;
@@ -1266,10 +1342,35 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (retry_scale > 0) {             // handed on by another group together with the scale its search wanted next
             hint = retry_scale;
             hint_budget = max_size;
+            local = true;
         }
-        const bool trust_hint = hint >= 1 && hint <= 63 && hint_budget == max_size;
-        if (tid == 0) L.scalars[S_ABORTS_LEFT] = 2;
-        if (trust_hint) {
+        const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
+        const bool trust_hint = hint_ok && (local || !L.scalars[S_DISTRUST]);
+        if (tid == 0) {
+            L.scalars[S_ABORTS_LEFT] = 2;
+            L.scalars[S_FOREIGN] = hint_ok && !local ? hint : 0;
+        }
+        // A frame started from a hint (no pilot) whose first pass is stopped with a verdict FAR from the hint -- a scene cut: the
+        // neighbour's answer said 23 and the checkpoint's projection says 3 -- starts over from the pilot: the verdict is a
+        // two-point extrapolation from the wrong end of the curve and used to cost such frames three to five passes; the pilot
+        // brackets the answer on a sample for a tenth of a pass.  Once per frame at most.
+        auto search_reset = [&](MdecSearch& st) {
+            mdec_search_init(st);
+            st.best = in_loop(st.best);
+            {       // (the zeros too: as loop-invariant constants they took two registers for the whole kernel -- and a scratch slot)
+                const int z = in_loop(0);
+                st.lo = z; st.staged = z; st.pad = z;
+                st.fail = (uint64_t)(uint32_t)z | ((uint64_t)(uint32_t)in_loop(0) << 32);
+                st.fs[0] = st.fs[1] = st.fb[0] = st.fb[1] = z;
+                st.gs[0] = st.gs[1] = st.gb[0] = st.gb[1] = z;
+            }
+        };
+        bool repilot = false;
+        int n_pass = 0, first_abort = 0, guess0 = 0;      // (first_abort, guess0: diagnostics)
+        int guess;
+        MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
+        for (;;) {
+        if (trust_hint && !repilot) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
             group_sync(1);
         } else {
@@ -1294,26 +1395,28 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             for (int b = 0; b < 6; b++) cfp[i][b] = pi < n_pilot ? cf[b] : 0.0f;
         }
         if (tid == 0) {
-            int h0 = hint;
+            L.scalars[S_PILOTED] = 1;
+            int h0 = hint_budget == max_size ? hint : 0;        // (not trusted, or for another budget: it still says where to look first)
+            if (repilot) h0 = L.scalars[S_REPILOT];
             if (h0 < 1) {
                 // no frame of its own yet: another group's last answer for the same budget is a good place to start looking
                 const int sh = L.scalars[S_SHARED_HINT];
                 if ((sh >> 8) == max_size) h0 = sh & 0xFF;
             }
-            if (h0 >= 2 && h0 <= 63) {
-                // frames handled back to back by one group tend to need the same scale: two evaluations confirm it
-                L.scalars[S_PILOT_N] = 2;
-                L.scalars[S_PILOT_SCALE0 + 0] = h0 - 1;
-                L.scalars[S_PILOT_SCALE0 + 1] = h0;
-            } else {
-                L.scalars[S_PILOT_N] = 4;
-                L.scalars[S_PILOT_SCALE0 + 0] = 1;
-                L.scalars[S_PILOT_SCALE0 + 1] = 2;
-                L.scalars[S_PILOT_SCALE0 + 2] = in_loop(4);
-                L.scalars[S_PILOT_SCALE0 + 3] = in_loop(8);
-            }
-            L.scalars[S_PILOT_LO] = in_loop(0);       // largest scale estimated not to fit
-            L.scalars[S_PILOT_HI] = in_loop(64);      // smallest scale estimated to fit
+            // The pilot is steered by the search's own two-point model (mdec_pilot_next, mdec_search.h; its state is a MdecSearch of
+            // ESTIMATES kept where the exact search's state will live -- that one is set up after the pilot): a hint is checked first
+            // (h0 - 1, h0), then the model's prediction and its neighbours -- two rounds and five evaluations on average, where
+            // bracketing by halves took three to five rounds of four (17 % of a group's time on scene-structured content).
+            MdecSearch st;
+            search_reset(st);
+            *srch = st;
+            const MdecPilot pl = mdec_pilot_next(st, h0, limit_bits, fixed_bits, 0);
+            L.scalars[S_PILOT_N] = pl.n;
+            L.scalars[S_PILOT_SCALE0 + 0] = pl.s[0];
+            L.scalars[S_PILOT_SCALE0 + 1] = pl.s[1];
+            L.scalars[S_PILOT_SCALE0 + 2] = pl.s[2];
+            L.scalars[S_PILOT_LO] = in_loop(0);       // rounds evaluated so far
+            L.scalars[S_PILOT_HI] = h0;               // the hint (the model's answer while it has nothing to go on)
         }
         for (;;) {
             group_sync(1);
@@ -1332,59 +1435,35 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
             group_sync(1);
             if (tid == 0) {
-                int p_lo = L.scalars[S_PILOT_LO], p_hi = L.scalars[S_PILOT_HI];
+                MdecSearch st = *srch;
                 for (int j = 0; j < np; j++) {
                     const int s = L.scalars[S_PILOT_SCALE0 + j];
-                    const long long est = (long long)L.scalars[S_PILOT_BITS0 + j] * nmb / n_pilot + fixed_bits;
-                    if (est <= limit_bits) { if (s < p_hi) p_hi = s; }
-                    else if (s > p_lo) p_lo = s;
+                    const int est = (int)((long long)L.scalars[S_PILOT_BITS0 + j] * nmb / n_pilot) + fixed_bits;
+                    mdec_search_note(st, s, est, est, limit_bits);
                     L.scalars[S_PILOT_BITS0 + j] = 0;
                 }
-                if (p_hi < p_lo) p_hi = 64;     // non-monotone estimate: trust the failure, keep looking above it
-                int n = 0;
-                if (p_hi - p_lo > 1 && p_lo < 63) {
-                    if (p_hi == 64) {
-                        // nothing fits yet: geometric steps upwards
-                        const int c[4] = {p_lo + (p_lo >> 1), 2 * p_lo, 3 * p_lo, 4 * p_lo};
-                        int last = p_lo;
-                        for (int j = 0; j < 4; j++) {
-                            const int sc = c[j] > 63 ? 63 : c[j];
-                            if (sc > last) { L.scalars[S_PILOT_SCALE0 + n++] = sc; last = sc; }
-                        }
-                    } else {
-                        const int gap = p_hi - p_lo - 1;
-                        if (gap <= kPilotMax) {
-                            for (int j = 1; j <= gap; j++) L.scalars[S_PILOT_SCALE0 + n++] = p_lo + j;
-                        } else {
-                            for (int j = 1; j <= kPilotMax; j++) L.scalars[S_PILOT_SCALE0 + n++] = p_lo + gap * j / (kPilotMax + 1);
-                        }
-                    }
-                }
-                L.scalars[S_PILOT_N] = n;
-                L.scalars[S_PILOT_LO] = p_lo;
-                L.scalars[S_PILOT_HI] = p_hi;
-                if (n == 0) L.scalars[S_PILOT_GUESS] = p_hi > 63 ? 63 : p_hi;
+                *srch = st;
+                const int round = L.scalars[S_PILOT_LO] + 1;
+                const MdecPilot pl = mdec_pilot_next(st, L.scalars[S_PILOT_HI], limit_bits, fixed_bits, round);
+                L.scalars[S_PILOT_N] = pl.n;
+                L.scalars[S_PILOT_LO] = round;
+                L.scalars[S_PILOT_SCALE0 + 0] = pl.s[0];
+                L.scalars[S_PILOT_SCALE0 + 1] = pl.s[1];
+                L.scalars[S_PILOT_SCALE0 + 2] = pl.s[2];
+                if (pl.n == 0) L.scalars[S_PILOT_GUESS] = pl.guess;
             }
         }
         }
-        const int guess = L.scalars[S_PILOT_GUESS];
+        guess = L.scalars[S_PILOT_GUESS];
+        if (STATS && !repilot) guess0 = guess;
         mark(2);   // pilot
 
         // ---- exact search (mdec_search.h): the state lives in LDS, thread 0 advances it between passes; every pass is
         //      described by two scalars
-        MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
         if (tid == 0) {
             L.scalars[S_NEXT_DRAW] = (int)next_draw;
             MdecSearch st;
-            mdec_search_init(st);
-            st.best = in_loop(st.best);
-            {       // (the zeros too: as loop-invariant constants they took two registers for the whole kernel -- and a scratch slot)
-                const int z = in_loop(0);
-                st.lo = z; st.staged = z; st.pad = z;
-                st.fail = (uint64_t)(uint32_t)z | ((uint64_t)(uint32_t)in_loop(0) << 32);
-                st.fs[0] = st.fs[1] = st.fb[0] = st.fb[1] = z;
-                st.gs[0] = st.gs[1] = st.gb[0] = st.gb[1] = z;
-            }
+            search_reset(st);
             MdecPass np;
             if (limit_bits < fixed_bits || bad_budget) {
                 np.done = 1; np.count_scale = 0; np.emit_scale = 0;
@@ -1400,7 +1479,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         group_sync(1);
 
-        int n_pass = 0, first_abort = 0;      // (first_abort: diagnostics)
         while (!L.scalars[S_DONE]) {
             const int count_scale = L.scalars[S_PASS_COUNT], emit_scale = L.scalars[S_PASS_EMIT];
             n_pass++;
@@ -1492,7 +1570,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     // mark -- read back from the records the macroblocks left (stage_alloc), by the whole judging wavefront, once
                     // per pass (kept as running sums they were six scalar instructions in every macroblock of every wavefront)
                     unsigned ck_s1 = 0, ck_sq = 0;
-                    if (judge && emit_scale) {
+                    // (a pass that has run out of staging room -- S_STG_NEXT past the area: offsets above 16 bits have spilled into the
+                    //  records' bit counts -- keeps the default margin: its stream is not going to be used anyway)
+                    const bool records_ok = L.scalars[S_STG_NEXT] <= job.stg_words;
+                    if (judge && emit_scale && records_ok) {
                         for (int t = lane; t < check_t; t += 64) {
                             const OrderPtr oe = (OrderPtr)(order_b + (uint32_t)t * 8u);
                             if ((int)oe[0] < 0) {
@@ -1516,14 +1597,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         // with tools/gpu_ckmargin_sweep.py: content whose answer flips between neighbouring scales gains 14 %
                         // over a fixed 5 % margin, stable content is unaffected).
                         int margin = (limit_bits - fixed_bits) / 50;
-                        if (emit_scale && done > 1 && done < nmb) {
+                        if (emit_scale && records_ok && done > 1 && done < nmb) {
                             const float n = (float)done, mean = (float)ck_s1 / n;      // of x = bits >> 2
                             float var = (float)ck_sq / n - mean * mean;
                             var = var > 0.0f ? var : 0.0f;
                             const float se = 4.0f * __builtin_sqrtf(var * n * (1.0f - n / (float)nmb)) * ((float)nmb / n);
                             margin = (int)(se * (float)job.ck_margin * 0.001f);
                         }
-                        const int g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, margin);
+                        int g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, margin);
+                        // A verdict FAR from where a PILOTED frame started is not taken: it is a two-point extrapolation from a quarter of
+                        // the pass, the pilot was a measurement of its own, and on pictures that are not the same everywhere (a quarter of
+                        // the frame full-contrast bars, the rest flat: answer 5, pilot 6, verdict 39) the quarter's rows over-weigh one
+                        // part -- such frames took five passes.  The pass runs to its end and the search goes on from what it counted.
+                        {
+                            const int cur = emit_scale ? emit_scale : count_scale + 1, far = cur > 8 ? cur >> 2 : 2;
+                            if (g && L.scalars[S_PILOTED] && (g - cur >= far || cur - g >= far)) g = 0;
+                        }
                         if (g) {
                             L.scalars[S_ABORT] = g | (n_pass << 8);
                             L.scalars[S_ABORTS_LEFT] = L.scalars[S_ABORTS_LEFT] - 1;
@@ -1900,7 +1989,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // launch used to last as long as the group that drew two such frames (noise +-8: 250 us against a median group's
                 // 170); retries are now drawn like tickets.  The result of a frame never depends on who encodes it or from which guess.
                 auto hand_on = [&](const MdecPass& np) -> bool {
-                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 || (unsigned)L.scalars[S_NEXT_DRAW] >= fresh_draws) return false;
+                    if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 ||
+                        (L.scalars[S_RUN_LEFT] == 0 && (unsigned)L.scalars[S_NEXT_DRAW] >= fresh_draws)) return false;
                     const unsigned slot = (unsigned)(atomicAdd(queue_state(job), 1ull << kQueueReservedShift) >> kQueueReservedShift) & kQueueMask;
                     if (atomicExch(&retry_slots(job)[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
                         atomicExch(&retry_slots(job)[slot], (unsigned)in_loop((int)kRetryEmpty));      // the group this slot belonged to has left: the frame stays here
@@ -1916,7 +2006,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     if (old_hint < 1 && (L.scalars[S_SHARED_HINT] >> 8) == max_size) old_hint = L.scalars[S_SHARED_HINT] & 0xFF;   // (a group's first frame starts from the previous launch's last answer)
                     L.scalars[S_HINT] = old_hint < 1 || L.scalars[S_PUSHED] ? np.emit_scale : old_hint;
                     L.scalars[S_HINT_BUDGET] = max_size;
+                    L.scalars[S_HINT_FRAME] = in_loop(-2);          // (not the neighbour's ANSWER: foreign)
                     L.scalars[S_PUSHED] = 1;
+                    if (L.scalars[S_FOREIGN]) {                     // the frame left with its answer unknown; its foreign hint was not it
+                        L.scalars[S_F_TRIED] = L.scalars[S_F_TRIED] + 1;
+                        L.scalars[S_F_WRONG] = L.scalars[S_F_WRONG] + 1;
+                        L.scalars[S_DISTRUST] = 1;
+                    }
                     return true;
                 };
                 if (aborted) {
@@ -1930,7 +2026,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_CNT_F] = 0; L.scalars[S_CNT_D] = 0; L.scalars[S_CK_DONE] = 0; L.scalars[S_CK_WAVES] = 0;
                     L.scalars[S_EMIT_BITS] = 0; L.scalars[S_EMIT_D] = 0; L.scalars[S_NNZ] = 0;
                     L.scalars[S_MB_NEXT] = 2 * kWavesPerGroup;
-                    (void)hand_on(np);
+                    const int vg = verdict & 0xFF, far = guess > 8 ? guess >> 2 : 2;
+                    if (n_pass == 1 && !L.scalars[S_PILOTED] && !np.done && (vg - guess >= far || guess - vg >= far)) {
+                        L.scalars[S_REPILOT] = vg;
+                        L.scalars[S_DONE] = 1;          // leaves the pass loop; the frame starts over from the pilot (below)
+                    } else {
+                        (void)hand_on(np);
+                    }
                 } else {
                 if (count_scale) {
                     const int tb = L.scalars[S_CNT_F] + fixed_bits;
@@ -1959,6 +2061,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (kStopAfter && tid == 0) L.scalars[S_DONE] = 1;
             group_sync(4);
         }
+        if (repilot || !L.scalars[S_REPILOT]) break;
+        repilot = true;
+        group_sync(4);          // (everybody has seen S_REPILOT and S_DONE; the pilot and the search start-up write the scalars again)
+        }
         n_done++;
         mark(3);   // passes
         if (L.scalars[S_DEFER]) {
@@ -1969,7 +2075,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             continue;
         }
         if (STATS && tid == 0 && f < PSXHIP_MDEC_TRACE_FRAMES)      // per-frame record: first guess | first abort verdict << 8 | answer << 16 | passes << 24
-            job.stats[PSXHIP_MDEC_STATS_FRAME0 + f] = (unsigned long long)(guess & 0xFF) | (unsigned long long)(first_abort & 0xFF) << 8 |
+            job.stats[PSXHIP_MDEC_STATS_FRAME0 + f] = (unsigned long long)(guess0 & 0xFF) | (unsigned long long)(first_abort & 0xFF) << 8 |
                                                       (unsigned long long)(L.scalars[S_RESULT] & 0xFF) << 16 | (unsigned long long)n_pass << 24;
         if (STATS && tid == 0) {
             pass_sum += (unsigned)n_pass;
@@ -1986,7 +2092,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (scale < 64 && f == job.n_frames - 1) *job.hint = (unsigned)scale | ((unsigned)max_size << 8);
             L.scalars[S_HINT] = scale < 64 ? scale : 0;
             L.scalars[S_HINT_BUDGET] = max_size;
+            L.scalars[S_HINT_FRAME] = f;
             L.scalars[S_PUSHED] = 0;
+            const int foreign = L.scalars[S_FOREIGN];
+            if (foreign) {
+                const int wrong = foreign != scale ? 1 : 0;
+                L.scalars[S_F_TRIED] = L.scalars[S_F_TRIED] + 1;
+                L.scalars[S_F_WRONG] = L.scalars[S_F_WRONG] + wrong;
+                L.scalars[S_DISTRUST] = wrong;
+            }
         }
         uint8_t* outp;
         psxhip_mdec_result_t* b_results;
@@ -2160,18 +2274,39 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     }
     // ---- the last workgroup to leave re-arms the ticket counters for the next launch (launches on one context are
     //      stream-ordered, see psxav_hip.h)
-    if (tid == 0) {
-        const unsigned left = atomicAdd(&job.ticket[1], 1u);       // groups gone | abandoned queue slots << 16
+    if (tid < 64) {       // (the group's first wavefront: lane 0 counts the group out, all 64 lanes re-arm the slots)
+        unsigned lo = 0, hi = 0;
+        if (tid == 0) {
+            unsigned tried = (unsigned)L.scalars[S_F_TRIED], wrong = (unsigned)L.scalars[S_F_WRONG];
+            if (tried > kTrustCap) { wrong = (wrong * kTrustCap + tried / 2) / tried; tried = kTrustCap; }
+            const unsigned long long mine = 1ull | (unsigned long long)wrong << kLeaveWrongShift | (unsigned long long)tried << kLeaveTriedShift;
+            const unsigned long long lw = atomicAdd(leave_word(job), mine) + mine;       // groups gone | abandoned queue slots << 16 | wrong << 32 | tried << 48
+            lo = (unsigned)lw;
+            hi = (unsigned)(lw >> 32);
+        }
+        lo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+        hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+        const unsigned left = lo - 1u;
         if ((left & 0xFFFFu) == gridDim.x - 1u) {
-            job.ticket[1] = 0u;
-            job.ticket[kStartedWord] = 0u;
             if (job.retry && (left >> 16)) {      // queue slots that were given up and never reserved still say so
-                const unsigned long long w = atomicAdd(queue_state(job), 0ull);
-                unsigned head = (unsigned)(w >> kQueueHeadShift) & kQueueMask;
+                // (all 64 lanes: with two launches in flight a group that finishes before every group of its launch has started may
+                //  not wait, so whole launches' worth of pop tickets are given up -- one thread storing 500 words one after the
+                //  other held the launch's end up by 12 us)
+                unsigned long long w = 0;
+                if (tid == 0) w = atomicAdd(queue_state(job), 0ull);
+                const unsigned wh = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32));
+                unsigned head = (wh >> (kQueueHeadShift - 32)) & kQueueMask;
                 if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
-                for (unsigned i = (unsigned)(w >> kQueueReservedShift) & kQueueMask; i < head; i++) retry_slots(job)[i] = kRetryEmpty;
+                for (unsigned i = ((wh >> (kQueueReservedShift - 32)) & kQueueMask) + (unsigned)tid; i < head; i += 64u) retry_slots(job)[i] = kRetryEmpty;
             }
-            *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
+            if (tid == 0) {
+                // the launch's verdict on foreign hints, for the launches after it (a launch that judged fewer than eight leaves it alone)
+                const unsigned all_wrong = hi & 0xFFFFu, all_tried = hi >> 16;
+                if (all_tried >= 8u) job.hint[kDistrustWord] = 4u * all_wrong > all_tried ? 1u : 0u;
+                *leave_word(job) = 0ull;
+                job.ticket[kStartedWord] = 0u;
+                *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
+            }
             __threadfence();
         }
     }
@@ -2334,6 +2469,27 @@ extern "C" int psxhip_mdec_pass_table(int width, int height, int large, uint32_t
     return n;
 }
 
+// Frame tickets of a launch of n_frames frames on `groups` persistent workgroups (ticket_run() in the kernel reads the result):
+// whole rounds of the grid in runs of 4 while at least four rounds are left, then whole rounds in runs of 2, and what remains --
+// less than two rounds -- as one round of runs of 2 when it is more than one frame per group, else as single frames.  Every
+// round of the grid is whole, so runs cost no balance: 1000 frames on 512 groups are 500 runs of 2 (as many frames per group as
+// single tickets give), 1250 are 512 runs of 2 and 226 single frames, 4000 are 512 runs of 4 and 976 of 2.
+// max_run: 1 = single frames only (the hand-out of the kernels before mdec-k3.7), 2 = no runs of 4.
+extern "C" void psxhip_mdec_ticket_plan(int n_frames, int groups, int max_run, int* t4, int* t2, int* n_tickets) {
+    int r = n_frames, a4 = 0, a2 = 0;
+    if (groups < 1) groups = 1;
+    if (max_run >= 4) { a4 = groups * (r / (4 * groups)); r -= 4 * a4; }
+    if (max_run >= 2) {
+        const int whole = groups * (r / (2 * groups));
+        a2 = whole;
+        r -= 2 * whole;
+        if (r > groups) { a2 += r / 2; r &= 1; }
+    }
+    *t4 = a4;
+    *t2 = a2;
+    *n_tickets = a4 + a2 + r;
+}
+
 extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     const int waves_ = a->large ? kWavesLarge : kWavesSmall;
     FrameJob job;
@@ -2355,6 +2511,9 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.ny = a->height / 16;
     job.nmb = job.nx * job.ny;
     job.n_frames = a->n_frames;
+    job.n_tickets = a->n_tickets;
+    job.t4 = a->t4;
+    job.t2 = a->t2;
     job.uniform_max_size = a->uniform_max_size;
     job.out_stride = a->out_stride;
     job.out_words = a->out_words;

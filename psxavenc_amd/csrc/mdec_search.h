@@ -149,6 +149,46 @@ PSX_HD int mdec_search_checkpoint(const MdecSearch& s, int a, int pa, int b, int
     return mdec_search_checkpoint_bits(s, a, pa, b, pb, limit_bits, fixed_bits, (int)((long long)room * margin_permille / 1000));
 }
 
+// The pilot (a sample of the frame's macroblocks, their AC bits at a few scales scaled up to the frame) steered by the same model:
+// the sample's estimates are recorded like evaluations (mdec_search_note with fbits = tbits: `lo` is then the highest scale
+// ESTIMATED not to fit, `best` the lowest estimated to fit -- a state of its own, never the exact search's), and the scales to try
+// next are the model's prediction and its neighbours.  `round` 0: nothing evaluated yet -- a hint h0 (2..63) is checked first
+// (h0 - 1, h0), without one two scales a factor of four apart give the model its two points.  Returns the scales to
+// evaluate next (at most 3), or n = 0 with the predicted answer.  Typically two rounds, five evaluations
+// (the bracketing by halving it replaces took three to five rounds of four).
+struct MdecPilot {
+    int n;          // scales to evaluate next (0: finished)
+    int s[3];       // ... the scales (unused entries 0)
+    int guess;      // n == 0: the predicted answer
+};
+PSX_HD MdecPilot mdec_pilot_next(const MdecSearch& s, int h0, int limit_bits, int fixed_bits, int round) {
+    MdecPilot r;
+    r.n = 0; r.s[0] = 0; r.s[1] = 0; r.s[2] = 0; r.guess = 0;
+    if (round == 0) {
+        const bool hinted = h0 >= 2 && h0 <= 63;
+        r.n = 2;
+        r.s[0] = hinted ? h0 - 1 : 2;
+        r.s[1] = hinted ? h0 : 8;
+        return r;
+    }
+    const int lo = s.lo;
+    const int hi = s.best > lo ? s.best : 64;       // (a fit below a failure: a non-monotone estimate -- trust the failure, look above it)
+    if (hi - lo <= 1 || lo >= 63 || round >= 6) {
+        r.guess = hi > 63 ? 63 : hi;
+        return r;
+    }
+    int p = mdec_search_predict(s, h0, limit_bits - fixed_bits, fixed_bits);
+    const int top = hi > 63 ? 63 : hi - 1;          // highest scale still open
+    if (p <= lo) p = lo + 1;
+    if (p > top) p = top;
+    const bool below = p - 1 > lo, above = p + 1 <= top;       // (no indexed stores: the struct stays in registers)
+    r.s[0] = below ? p - 1 : p;
+    r.s[1] = below ? p : (above ? p + 1 : 0);
+    r.s[2] = below && above ? p + 1 : 0;
+    r.n = 1 + (below ? 1 : 0) + (above ? 1 : 0);
+    return r;
+}
+
 // what to do next.  `guess` = predicted answer (used until something has been evaluated), `fixed_bits` = the
 // scale-independent part of the total (DC + end-of-block + end-of-frame codes)
 PSX_HD MdecPass mdec_search_next(const MdecSearch& s, int guess, int limit_bits, int fixed_bits) {

@@ -85,6 +85,7 @@ struct psxhip_mdec_ctx {
     hipEvent_t lane_in[2], lane_done[2];
     bool lane_pending[2];           // lane_done[l] has been recorded and no caller stream has been ordered behind it yet
     int retry_patience;
+    int max_run;                    // longest run of consecutive frames a frame ticket may be (4; PSXHIP_MDEC_RUN: experiments)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
     int ck_margin;
@@ -238,6 +239,12 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     c->prio_pattern = 0x2EE01u;      // younger group raised 6 steps in 8, older 1 (re-swept on mdec-k2.23: tools/gpu_prio_sweep.py)
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
+    // Runs of consecutive frames per ticket are built and measured, and NOT the default: what made
+    // scene-structured content fast is the trust policy (pilot when foreign hints fail); on top of it runs of 2 / 4 changed mixed
+    // content by -2 .. +5 % and cost uniform content 10 % with two launch lanes (groups that finish while their launch's other
+    // groups have yet to start may not wait for handed-on frames).  PSXHIP_MDEC_RUN=2 / 4 turns them on.
+    c->max_run = 1;
+    if (const char* e = getenv("PSXHIP_MDEC_RUN")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) c->max_run = v; }      // experiments: 1 = single-frame tickets
 
     c->lanes = 1;
     HIP_TRY(hipMalloc((void**)&c->d_ticket, kLanes * 128 * sizeof(unsigned int)), PSXHIP_ENOMEM);
@@ -337,7 +344,10 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
     a.out_tile = c->out_words - 2;
     a.max_frame_size = c->max_frame_size;
     a.stg_words = c->stg_words;
-    a.grid = n_frames < c->groups_max ? n_frames : c->groups_max;
+    // frame tickets: runs of consecutive frames (a group encodes neighbours in time one after the other: the hint that is worth
+    // trusting), long runs first (psxhip_mdec_ticket_plan)
+    psxhip_mdec_ticket_plan(n_frames, c->groups_max, c->max_run, &a.t4, &a.t2, &a.n_tickets);
+    a.grid = a.n_tickets < c->groups_max ? a.n_tickets : c->groups_max;
     a.large = c->large || small_batch;
     a.stream = stream;
     a.d_ticket = c->d_ticket + 128 * lane;
@@ -346,6 +356,11 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
     // frame, and a group holds FEW: from about eight frames per group on the fresh-frame tickets level the groups by themselves,
     // and a frame restarted on another XCD is read from HBM again (10 000 x 640x480: -1 % time, +8 % traffic with the queue)
     const bool queue = c->d_retry && n_frames > a.grid && n_frames <= 8 * a.grid && n_frames < c->retry_cap;
+    // (experiments, PSXHIP_MDEC_SPARE: a launch of at most one run per group has CU slots to spare when runs left some empty -- 1000 frames:
+    //  500 runs on 512 slots -- and the kernel lets groups start without a ticket, to take handed-on frames only.  Measured: they
+    //  never get any, because a group that finds not every group of its launch started may not wait and gives its place up at
+    //  once; not used.)
+    if (queue && a.n_tickets < c->groups_max && n_frames > a.n_tickets && getenv("PSXHIP_MDEC_SPARE")) a.grid = c->groups_max;
     a.d_retry = queue ? c->d_retry + (size_t)lane * c->retry_cap : nullptr;
     a.retry_cap = queue ? c->retry_cap : 0;
     a.retry_patience = c->retry_patience;

@@ -50,6 +50,12 @@ inline void pick_chunking(long long total_units, int rows, int device, int* chun
     *warmup_units = p >= 1024 ? 32 : 16;     // noisy material converges within a few units, tonal material not within 1024 either
 }
 
+}  // namespace
+extern "C" void psxhip_adpcm_pick_chunking(long long total_units, int rows, int device, int* chunk_units, int* warmup_units) {
+    pick_chunking(total_units, rows, device, chunk_units, warmup_units);
+}
+namespace {
+
 // Device scratch of the host-buffer entry points.  The reference calls psx_audio_spu_encode once per 28 samples and
 // psx_audio_xa_encode once per sector (filefmt.c:243,184): allocating half a dozen device buffers per call would cost far
 // more than the encode, so every host thread keeps its scratch buffers between calls (grown on demand, released by

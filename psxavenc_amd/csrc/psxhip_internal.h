@@ -7,7 +7,9 @@
 #include "../../include/psxav_hip.h"
 
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
-#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.6"
+#define PSXHIP_MDEC_KERNEL_REV "mdec-k3.7"
+/* ... and with every change to the ADPCM kernels (round 4's kernels count as adpcm-k4.0) */
+#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.0"
 
 #ifdef __cplusplus
 extern "C" {
@@ -19,6 +21,7 @@ typedef struct {
 	size_t frame_stride;
 	int width, height, codec;
 	int n_frames;                         /* over all batches */
+	int n_tickets, t4, t2;                /* frame tickets: runs of 4, runs of 2, single frames (psxhip_mdec_ticket_plan) */
 	int uniform_max_size;
 	size_t out_stride;
 	int out_words;      /* LDS dwords of the frame image tile: out_tile + 2 */
@@ -45,6 +48,7 @@ hipError_t psxhip_mdec_upload_tables(void);
 hipError_t psxhip_mdec_set_max_lds(int codec, size_t bytes);
 int psxhip_mdec_pass_order(int width, int height, int large, uint32_t *out, int cap);
 int psxhip_mdec_pass_table(int width, int height, int large, uint32_t *out /* [2 * (n + 1)] */, int cap);
+void psxhip_mdec_ticket_plan(int n_frames, int groups, int max_run, int *t4, int *t2, int *n_tickets);
 hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t *a);
 hipError_t psxhip_mdec_stage_in_launch(const void *src_mapped, void *d_dst, size_t bytes, void *stream);
 hipError_t psxhip_mdec_fdct_launch(const int16_t *d_in, int16_t *d_out, int n_blocks, void *stream);
@@ -76,6 +80,26 @@ int psxhip_adpcm_call_stage_max(void);
 int psxhip_xa_assemble_device_bits(int device, const uint8_t *d_units, int n_sectors, int format, int stereo, int frequency, int bits,
                                    int file_number, int channel_number, int first_lba, const uint8_t *d_eof_flags, uint32_t eof_bits,
                                    uint8_t *d_out, void *stream);
+
+int psxhip_xa_assemble_scatter(int device, const uint8_t *d_units, int n_sectors, int format, int stereo, int frequency, int bits,
+                               int file_number, int channel_number, int first_lba, const uint8_t *d_eof_flags, uint32_t eof_bits,
+                               uint8_t *d_out, const int32_t *d_dst_sector, int n_streams, size_t units_stream_stride,
+                               size_t out_stream_stride, void *stream);
+/* video sectors of muxed STR streams, built on the device (adpcm_kernels.hip: str_video_sector_kernel) */
+typedef struct {
+	const uint8_t *d_bs;                 /* the frames' bitstreams */
+	size_t bs_stride, bs_stream_stride;
+	const psxhip_mdec_result_t *d_res;   /* [n_streams][frames_per_stream] */
+	int frames_per_stream;
+	const int32_t *d_tab;                /* [n_entries][4]: slot in the stream, frame (-2: zero sector), byte offset into the bitstream, the frame's budget */
+	int n_entries, n_streams;
+	int format, sector_size;
+	int xa_file, xa_channel, video_id, width, height;
+	uint8_t *d_out;
+	size_t out_stream_stride;
+} psxhip_str_video_job_t;
+int psxhip_str_video_sectors_launch(int device, const psxhip_str_video_job_t *a, void *stream);
+void psxhip_adpcm_pick_chunking(long long total_units, int rows, int device, int *chunk_units, int *warmup_units);
 
 void psxhip_set_error(const char *fmt, ...);
 

@@ -36,3 +36,26 @@ extern "C" int search_sim(const int* tb, const int* fb, int limit_bits, int fixe
     if (st.best < 64 && st.staged != st.best) return -2;
     return st.best;
 }
+
+// The pilot's policy (mdec_pilot_next) on an ESTIMATED curve est[s] (the sample's bits scaled up to the frame): returns its guess;
+// *rounds = rounds used, *evals = scales evaluated.
+extern "C" int pilot_sim(const int* est, int limit_bits, int fixed_bits, int h0, int* rounds, int* evals) {
+    MdecSearch st;
+    mdec_search_init(st);
+    int r = 0, ne = 0, guess = 0;
+    for (;; r++) {
+        const MdecPilot pl = mdec_pilot_next(st, h0, limit_bits, fixed_bits, r);
+        guess = pl.guess;
+        const int n = pl.n;
+        if (n == 0) break;
+        if (n < 0 || n > 3 || r > 20) return -1;
+        for (int j = 0; j < n; j++) {
+            if (pl.s[j] < 1 || pl.s[j] > 63) return -2;
+            mdec_search_note(st, pl.s[j], est[pl.s[j]], est[pl.s[j]], limit_bits);
+            ne++;
+        }
+    }
+    *rounds = r;
+    *evals = ne;
+    return guess;
+}

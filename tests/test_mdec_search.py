@@ -19,6 +19,7 @@ def sim(tmp_path_factory):
     L = C.CDLL(so)
     ip = C.POINTER(C.c_int)
     L.search_sim.argtypes = [ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+    L.pilot_sim.argtypes = [ip, C.c_int, C.c_int, C.c_int, ip, ip]
     return L
 
 
@@ -80,6 +81,36 @@ def test_search_returns_first_fit(sim, kind):
     assert passes.max() <= 64
     if kind == "smooth":
         assert np.mean(passes[0::4]) < 1.2
+
+
+@pytest.mark.parametrize("kind", ["smooth", "bumpy", "flat"])
+def test_pilot_policy_finds_the_first_fit_of_its_estimate_in_few_rounds(sim, kind):
+    """mdec_pilot_next (round 5: the pilot steered by the search's two-point model instead of bracketing by halves): on a monotone
+    estimate it returns exactly the first scale that fits, whatever the hint; on a bumpy one a scale next to it; two to three rounds
+    and about five evaluations on average, never more than six rounds"""
+    rng = np.random.default_rng({"smooth": 11, "bumpy": 12, "flat": 13}[kind])
+    rounds, evals, exact, near, total = [], [], 0, 0, 0
+    for _ in range(3000):
+        fixed = int(rng.integers(3000, 30000))
+        tb, _ = curve(rng, fixed, kind)
+        limit = int(rng.integers(fixed + 500, 140000))
+        want = min(first_fit(tb, limit), 63)
+        est = np.ascontiguousarray(tb, dtype=np.int32)
+        for h0 in (0, want, max(1, want - 1), min(63, want + 3), int(rng.integers(1, 64))):
+            r, e = C.c_int(), C.c_int()
+            got = sim.pilot_sim(est.ctypes.data_as(C.POINTER(C.c_int)), limit, fixed, h0, C.byref(r), C.byref(e))
+            assert 1 <= got <= 63, (kind, limit, fixed, h0, got)
+            assert r.value <= 6
+            total += 1
+            exact += got == want
+            near += abs(got - want) <= 1
+            rounds.append(r.value)
+            evals.append(e.value)
+            if kind == "smooth":
+                assert got == want or r.value == 6, (limit, fixed, h0, got, want, r.value)
+    assert np.mean(rounds) < 3.2 and np.mean(evals) < 8.0, (np.mean(rounds), np.mean(evals))
+    assert exact >= 0.93 * total and near >= (0.99 if kind == "smooth" else 0.95) * total, (kind, exact, near, total)
+    print(kind, "rounds", np.mean(rounds), "evaluations", np.mean(evals), "exact", exact / total)
 
 
 def test_overflowing_emit_is_not_trusted(sim):

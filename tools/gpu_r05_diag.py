@@ -111,6 +111,7 @@ def stats_run(bb, warm):
     r["stopped_at_checkpoint"] = int((ab != 0).sum())
     c = collections.Counter(zip(guess.tolist(), ab.tolist(), ans.tolist(), np_.tolist()))
     r["top_cases_guess_abort_answer_passes_count"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[1])[:10]]
+    r["cases_with_3_or_more_passes"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[0][3] * 1000 - x[1]) if k[3] >= 3][:16]
     ph = np.array(s[8 + 4096:8 + 4096 + 16], dtype=np.float64)
     r["phase_share_pct_ticket_resetdc_pilot_passes_scanmerge_writeout"] = np.round(100 * ph[:6] / max(1.0, ph[:6].sum()), 1).tolist()
     r["barrier_wait_pct_of_residency"] = round(100.0 * ph[6] / max(1.0, ph[7]), 1)

@@ -16,3 +16,4 @@ bash tools/gpu_rocprof_mdec.sh v3_32k --codec 1 --width 640 --height 480 --budge
 bash tools/gpu_rocprof_mdec.sh str_cycle --budget-cycle 16128,18144,18144,18144 --launches-per-step 200 > $O/prof_str_cycle.log 2>&1
 bash tools/gpu_rocprof_mdec.sh v3dc_8k --codec 2 --launches-per-step 200 > $O/prof_v3dc_8k.log 2>&1
 for t in v3_32k str_cycle v3dc_8k; do echo "=== $t"; head -6 $O/prof_$t/summary.txt | cut -c1-170; cut -c1-300 $O/prof_$t/bench_line.json; done
+find gpurun_out -name "*.db" -delete; du -sh gpurun_out

@@ -13,6 +13,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def counters_json(src, sub, like):
+    """the same from summary.json (tools/rocpd_summary.py --json), when the databases did not travel back"""
+    try:
+        d = json.load(open(os.path.join(src, "summary.json")))
+    except Exception:
+        return {}
+    key = like.strip("%")
+    out = {}
+    for path, v in d.items():
+        if "/%s/" % sub not in path:
+            continue
+        for k, cs in v["counters"].items():
+            if key in k:
+                for cn, (avg, n) in cs.items():
+                    out[cn] = (avg, n)
+    return out
+
+
 def counters(db, like):
     c = sqlite3.connect(db)
     out = {}
@@ -54,6 +72,12 @@ def main():
         sq = {}
         for db in glob.glob(os.path.join(src, "sq", "**", "*.db"), recursive=True):
             sq = counters(db, like)
+        if not fetch:
+            fetch = counters_json(src, "fetch", like).get("FETCH_SIZE")
+        if not write:
+            write = counters_json(src, "write", like).get("WRITE_SIZE")
+        if not sq:
+            sq = counters_json(src, "sq", like)
         key = line["roofline"].get("traffic_key")
         if fetch and write and key:
             idx[key] = {

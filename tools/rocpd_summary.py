@@ -30,5 +30,32 @@ def summarise(path):
         print("no counters:", e)
 
 
-for p in sys.argv[1:]:
+def as_json(path):
+    """{"kernels": {name: [calls, avg_ns]}, "counters": {kernel: {counter: [avg per dispatch, samples]}}}"""
+    c = sqlite3.connect(path)
+    out = {"kernels": {}, "counters": {}}
+    try:
+        for name, n, avg in c.execute("select name, count(*), avg(end-start) from kernels group by name"):
+            out["kernels"][name] = [n, avg]
+    except sqlite3.Error:
+        pass
+    try:
+        for k, cn, n, avg in c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+            out["counters"].setdefault(k, {})[cn] = [avg, n]
+    except sqlite3.Error:
+        pass
+    return out
+
+
+args = sys.argv[1:]
+json_out = None
+if "--json" in args:          # also write the numbers as JSON (the databases are too large to travel back from the GPU box)
+    i = args.index("--json")
+    json_out = args[i + 1]
+    del args[i:i + 2]
+for p in args:
     summarise(p)
+if json_out:
+    import json
+    with open(json_out, "w") as fh:
+        json.dump({p: as_json(p) for p in args}, fh, indent=1)
