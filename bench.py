@@ -141,6 +141,14 @@ def _profile_traffic(key):
         e = idx.get(key)
         if e:
             return e["traffic_bytes_per_launch"], e["source"], e
+        # no PMC pass of exactly this library / kernel revision: the newest one of the same workload, SAID to be of another revision
+        # (a lookup that silently missed left "traffic": null in a driver-run child)
+        wl = key.split(" | ")[0]
+        same = sorted((k for k in idx if k.split(" | ")[0] == wl), key=lambda k: [int(x) if x.isdigit() else x for x in __import__("re").split(r"(\d+)", k.split(" | ")[-1])])
+        if same:
+            e = dict(idx[same[-1]])
+            e["measured_on"] = same[-1].split(" | ")[-1]
+            return e["traffic_bytes_per_launch"], e["source"] + " (counters of %s, not of this revision)" % e["measured_on"], e
     except Exception:
         pass
     return None, None, None
@@ -280,6 +288,7 @@ def _main():
                          "--steps 20 to time over ten seconds of GPU work: 4800 launches of 1000 320x240 frames)")
     ap.add_argument("--audio-kind", type=int, default=0, help="xacd: synthetic material (psxhip_synth_pcm_device kind): 0 two tones + noise "
                     "floor -- tonal, start-state guesses do not converge, the hard case and the default; 2 white noise; 5 gated tone")
+    ap.add_argument("--str-streams", type=int, default=8, help="strcd: independent streams per psxhip_str_encode_device call (their XA tracks share the verify passes)")
     ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
     ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
@@ -291,6 +300,9 @@ def _main():
                     help="sbs: per-frame budgets cycling over this comma-separated list instead of one uniform --budget, e.g. "
                          "16128,18144,18144,18144 = what encode_sector_str asks for at 320x240 15 fps 2x speed (mdec.c:768-775; config 3's video leg alone, device-resident)")
     ap.add_argument("--amp", type=int, default=None, help="synthetic noise amplitude (4: final scale 3; 8: scale 5-6)")
+    ap.add_argument("--content", choices=["uniform", "mixed"], default="uniform",
+                    help="sbs: uniform = every frame the same noise amplitude (--amp; the headline), mixed = the scene-structured sequence of "
+                         "psxavenc_amd/mixed.py (scenes of 5..30 frames at noise +-2..40, ~5 %% hand-made frames), batch b = frames [b n, (b + 1) n) of it")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="sbs: contexts / streams the launches are dealt over (default 1: in-order launches on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -375,7 +387,12 @@ def _main():
         enc.set_lanes(lanes)
     geo = query_geometry(args.codec, w, h, budget, device=local_rank)
     # `nb` distinct batches of this rank's frames: batch b = the same frame indices drawn with seed + b
-    d_batches = [synth.frames_device(w, h, args.seed + b, first, n, args.amp, device=local_rank) for b in range(nb)]
+    if args.content == "mixed":
+        from psxavenc_amd import mixed
+        whole = mixed.frames_device(w, h, args.seed, first * nb, n * nb, device=local_rank)
+        d_batches = [whole[b * n:(b + 1) * n] for b in range(nb)]
+    else:
+        d_batches = [synth.frames_device(w, h, args.seed + b, first, n, args.amp, device=local_rank) for b in range(nb)]
     d_frames = d_batches[0]
     ostride = (budget + 3) & ~3
     # --budget-cycle: frame i of the job (not of the rank's share) gets cycle[i % len]: any rank can budget its own range
@@ -501,7 +518,8 @@ def _main():
                 secondary.update(_secondary_configs(args))
 
     version = _lib.lib().psxhip_version().decode()
-    wl_key = "sbs codec=%d %dx%d budget=%s frames=%d amp=%d | %s" % (args.codec, w, h, ("%d" % budget) if not cycle else "cycle(" + args.budget_cycle + ")", n, args.amp, version)
+    wl_key = "sbs codec=%d %dx%d budget=%s frames=%d %s | %s" % (args.codec, w, h, ("%d" % budget) if not cycle else "cycle(" + args.budget_cycle + ")", n,
+                                                                  ("amp=%d" % args.amp) if args.content == "uniform" else "content=mixed", version)
     traffic, traffic_src, pmc = _profile_traffic(wl_key)
     # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds its SIMD's issue slot for 4 cycles;
     # instructions per launch come from the same committed PMC pass as the traffic (SQ_INSTS_VALU).
@@ -522,6 +540,7 @@ def _main():
 
     if rank == 0:
         headline = args.codec == 0 and w == 320 and h == 240
+        sec_summary = _secondary_summary(secondary)
         line = {
             "metric": "bs_v2_320x240_frames_per_sec" if headline else "bs_%s_%dx%d_frames_per_sec" % (["v2", "v3", "v3dc"][args.codec], w, h),
             "value": round(value, 2),
@@ -537,13 +556,16 @@ def _main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": "sbs %s: %s synthetic %dx%d NV21 frames per launch (%d per GPU), %d launches per step cycling over %d distinct "
-                                   "batches, frame_max_size %d, noise +-%d; inputs resident in HBM, outputs stay in HBM (no D2H inside the "
+                                   "batches, frame_max_size %d, %s; inputs resident in HBM, outputs stay in HBM (no D2H inside the "
                                    "timed region)"
                                    % (["v2", "v3", "v3dc"][args.codec], ("%d" % args.total_frames) if strong else ("%d x %d" % (world, n)), w, h, n,
-                                      lps, nb, budget, args.amp),
+                                      lps, nb, budget, ("noise +-%d" % args.amp) if args.content == "uniform" else "scene-structured content (psxavenc_amd/mixed.py)"),
                        "preset": args.config, "baseline_config": args.baseline_config,
                        "frames_per_gpu_per_launch": n, "launches_per_step": lps, "distinct_batches": nb, "width": w, "height": h,
                        "frame_max_size": budget, "budget_cycle": cycle,
+                       "secondary_summary": sec_summary,
+                       "in_order_frames_per_sec": round(n / (kstat["mean"] * 1e-3), 1) if ns == 1 else None,
+                       "in_order_note": "every launch waiting for the one before (one launch lane): n / roofline.kernel_ms; `value` is the two-lane rate" if lanes > 1 else None,
                        "parallelism": "frames sharded x%d (contiguous ranges per rank), no data-path collective" % world,
                        "kernel_shape": {"groups_per_cu": geo.groups_per_cu, "wavefronts_per_group": geo.wavefronts_per_group,
                                         "image_tile_bytes": geo.image_tile_bytes, "frames_in_flight": geo.frames_in_flight},
@@ -556,7 +578,8 @@ def _main():
                           "roofline_achieved_gbs": round(r[3], 2), "roofline_frac": round(r[3] / HBM_PEAK_GBS, 6),
                           "quant_scale_sum": int(q[0]), "results_sane": bool(q[1])} for i, (r, q) in enumerate(zip(per_rank, scale_sum))],
             "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "frac_overlapped": overlapped["frac"] if overlapped else None, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_key": wl_key, "kernel_ms": kstat["mean"], "kernel_ms_stats": kstat,
                          "launches_timed": (kstat.get("launches") if lanes > 1 else args.steps * lps),
                          "kernel_ms_method": ("strict stream order (one launch lane), measured after the timed region: one HIP event pair per block of %d back-to-back "
@@ -578,10 +601,42 @@ def _main():
         dist.destroy_process_group()
 
 
+def _secondary_summary(sec):
+    """the secondaries' headline numbers in a few dozen bytes, inside `config` (a driver record keeps `config` whole and the tail of
+    the line only): frames/s (sectors/s for the ADPCM / STR children)"""
+    if not sec:
+        return None
+    out = {}
+
+    def g(path, key):
+        d = sec
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+            if d is None:
+                return
+        out[key] = d
+    g(("noise_amp_8", "two_lanes", "frames_per_sec"), "noise_amp_8_two_lanes")
+    g(("noise_amp_8", "one_lane_in_order", "frames_per_sec"), "noise_amp_8_in_order")
+    g(("cold_context", "first_four_launches_two_lanes", "frames_per_sec"), "cold_context_two_lanes")
+    g(("cold_context", "first_launch_alone", "frames_per_sec"), "cold_context_first_launch")
+    g(("mixed_content", "two_lanes", "frames_per_sec"), "mixed_content_two_lanes")
+    g(("mixed_content", "one_lane_in_order", "frames_per_sec"), "mixed_content_in_order")
+    g(("mixed_content", "four_batches_one_launch", "frames_per_sec"), "mixed_content_batch_list")
+    g(("mixed_content", "distinct_scales"), "mixed_content_distinct_scales")
+    g(("mixed_content", "passes", "passes_per_frame"), "mixed_content_passes_per_frame")
+    g(("sbs_v3_1250", "value"), "sbs_v3_1250_frames_per_sec")
+    g(("xacd_config5", "value"), "xacd_config5_sectors_per_sec")
+    g(("strcd_config3", "value"), "strcd_config3_device_resident_sectors_per_sec")
+    g(("strcd_config3", "config", "legs", "host_buffers_one_stream", "sectors_per_sec"), "strcd_config3_host_buffers_sectors_per_sec")
+    g(("per_call_drop_in", "encode_frame_bs_320x240_v2", "us_per_call_median"), "per_call_encode_frame_bs_us")
+    return out
+
+
 def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
     """Untimed extras of the default line (after the timed region, rank 0, one GPU): the same batch size on content whose
     answer flips between neighbouring scales (noise +-8), and on a COLD context (no hint from a previous launch: every
     group's first frame runs the pilot).  The headline is the warm steady state; these are what it does not show."""
+    import numpy as np
     from psxavenc_amd import synth
     from psxavenc_amd.mdec import MdecEncoder
     out = {}
@@ -652,25 +707,124 @@ def _secondary_sbs(args, torch, dev, local_rank, w, h, budget, n, first):
         enc.close()
     except Exception as e:
         out["four_batches_one_launch"] = {"error": repr(e)}
-    try:
-        enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
-        b8 = [synth.frames_device(w, h, args.seed + 100 + b, first, n, 8, device=local_rank) for b in range(4)]
-        timed(enc, b8, 8)
-        ms = timed(enc, b8, 64)
-        sc, cn = d_res[:, 0].cpu().unique(return_counts=True)
-        out["noise_amp_8"] = {"frames_per_sec": round(n / ms * 1e3, 1), "kernel_ms": round(ms, 5), "launches": 64,
-                              "quant_scale_hist_last_launch": {str(int(s)): int(c) for s, c in zip(sc.tolist(), cn.tolist())}}
-        enc.close()
-        b4 = [synth.frames_device(w, h, args.seed + 200 + b, first, n, args.amp, device=local_rank) for b in range(2)]
-        cold = []
-        for t in range(5):
-            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)      # a fresh context has no hint
-            torch.cuda.synchronize()
-            cold.append(timed(enc, [b4[t % 2]], 1))
+    o4 = [(torch.zeros_like(d_out), torch.zeros_like(d_res)) for _ in range(4)]
+
+    def rates(batches, launches=64):
+        """frames/s for one launch of `n` frames at a time over four distinct batches: every launch waiting for the one before (one
+        lane), the way the headline is measured (two lanes: results lag one call), and the four batches as ONE batch list"""
+        r = {}
+        for lanes in (1, 2):
+            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+            if lanes > 1:
+                enc.set_lanes(2)
+
+            def run(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record()
+                for k in range(reps):
+                    enc.encode_frames_device(batches[k % 4], budget, d_out=o4[k % 4][0], d_results=o4[k % 4][1])
+                if lanes > 1:
+                    enc.fence()
+                b.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+            run(8)
+            ms = min(run(launches), run(launches))
+            r["one_lane_in_order" if lanes == 1 else "two_lanes"] = {"frames_per_sec": round(n / ms * 1e3, 1), "ms_per_launch": round(ms, 5), "launches": launches}
             enc.close()
-        cold.sort()
-        out["cold_context_first_launch"] = {"frames_per_sec": round(n / cold[len(cold) // 2] * 1e3, 1), "kernel_ms_median": round(cold[len(cold) // 2], 5),
-                                            "kernel_ms_min": round(cold[0], 5), "kernel_ms_max": round(cold[-1], 5), "contexts": len(cold)}
+        enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+        lst = [(batches[i], o4[i][0], o4[i][1]) for i in range(4)]
+
+        def run4(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                enc.encode_batches_device(lst, budget)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+        run4(3)
+        ms4 = min(run4(16), run4(16))
+        r["four_batches_one_launch"] = {"frames_per_sec": round(4 * n / ms4 * 1e3, 1), "ms_per_launch": round(ms4, 5)}
+        enc.close()
+        allr = torch.cat([o[1][:, 0] for o in o4]).cpu()
+        sc, cn = allr.unique(return_counts=True)
+        r["quant_scale_hist"] = {str(int(a)): int(b) for a, b in zip(sc.tolist(), cn.tolist())}
+        return r
+
+    def cold(batches, lanes, launches):
+        """a FRESH context (no hint from a previous launch, no verdict on foreign hints): its first `launches` launches"""
+        ts = []
+        for t in range(5):
+            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+            if lanes > 1:
+                enc.set_lanes(2)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for k in range(launches):
+                enc.encode_frames_device(batches[(t + k) % len(batches)], budget, d_out=o4[k % 4][0], d_results=o4[k % 4][1])
+            if lanes > 1:
+                enc.fence()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / launches)
+            enc.close()
+        ts.sort()
+        return {"frames_per_sec": round(n / ts[len(ts) // 2] * 1e3, 1), "ms_per_launch_median": round(ts[len(ts) // 2], 5), "ms_min": round(ts[0], 5),
+                "ms_max": round(ts[-1], 5), "contexts": len(ts), "launches_per_context": launches, "launch_lanes": lanes}
+
+    def passes_hist(batches):
+        """from the diagnostics instantiation (PSXHIP_MDEC_STATS=1, its own context): passes per frame over one cycle of the four batches"""
+        import ctypes as C
+        from psxavenc_amd import _lib
+        os.environ["PSXHIP_MDEC_STATS"] = "1"
+        try:
+            enc = MdecEncoder(args.codec, w, h, max_frame_size=budget, device=local_rank)
+        finally:
+            del os.environ["PSXHIP_MDEC_STATS"]
+        t = (C.c_ulonglong * 8)()
+        for k in range(4):
+            enc.encode_frames_device(batches[k], budget, d_out=d_out, d_results=d_res)
+        torch.cuda.synchronize()
+        _lib.lib().psxhip_mdec_read_stats(enc._h, t, 8, 1)
+        for k in range(4):
+            enc.encode_frames_device(batches[k], budget, d_out=d_out, d_results=d_res)
+        torch.cuda.synchronize()
+        _lib.lib().psxhip_mdec_read_stats(enc._h, t, 8, 1)
+        enc.close()
+        st = list(t)
+        return {"frames": 4 * n, "passes_per_frame": round(st[1] / float(4 * n), 4), "frames_started_incl_handed_on": st[0],
+                "passes_hist_per_frame_start_0_1_2_3_4_5plus": st[2:8]}
+
+    try:
+        b8 = [synth.frames_device(w, h, args.seed + 100 + b, first, n, 8, device=local_rank) for b in range(4)]
+        r8 = rates(b8)
+        out["noise_amp_8"] = dict(r8, frames_per_sec=r8["two_lanes"]["frames_per_sec"], measured_like="the headline: one context, one stream, two launch lanes, four distinct batches",
+                                  passes=passes_hist(b8))
+        b4 = [synth.frames_device(w, h, args.seed + 200 + b, first, n, args.amp, device=local_rank) for b in range(4)]
+        c2 = cold(b4, 2, 4)
+        out["cold_context"] = {"first_four_launches_two_lanes": c2, "first_launch_alone": cold(b4, 1, 1), "frames_per_sec": c2["frames_per_sec"],
+                               "note": "a fresh context: no hint from a previous launch, every group's first frame runs the pilot"}
+        # ---- content that is not the friendliest point of the space (VERDICT r04 #1): the scene-structured sequence of
+        #      psxavenc_amd/mixed.py -- runs of 5..30 similar frames, cuts between noise amplitudes 2..40, one frame in twenty flat /
+        #      hard edges / escape-heavy -- 4 x n frames, one n-frame launch at a time
+        if (w, h, budget, args.codec) == (320, 240, 8192, 0):
+            from psxavenc_amd import mixed
+            whole = mixed.frames_device(w, h, args.seed, first, 4 * n, device=local_rank)
+            bm = [whole[i * n:(i + 1) * n] for i in range(4)]
+            rm = rates(bm)
+            out["mixed_content"] = dict(rm, frames_per_sec=rm["two_lanes"]["frames_per_sec"], passes=passes_hist(bm), cold_context=cold(bm, 2, 4),
+                                        content="psxavenc_amd/mixed.py: %d frames, scenes of 5..30 frames at noise +-2..40, ~5 %% hand-made frames (flat, hard edges, escapes); "
+                                                "integer-only, frame i a function of (seed, i)" % (4 * n),
+                                        distinct_scales=len(rm["quant_scale_hist"]))
+            import oracle_lib as O
+            idx = np.linspace(0, 4 * n - 1, 48).astype(np.int64)
+            fr = whole[torch.from_numpy(idx).to(dev)].cpu().numpy()
+            want, want_res, rc = O.mdec_encode(args.codec, w, h, fr, budget)
+            got = torch.cat([o[0] for o in o4])[torch.from_numpy(idx).to(dev)].cpu().numpy()[:, :budget]
+            out["mixed_content"]["parity"] = {"frames_checked": int(idx.size), "bit_exact": bool(rc == 0 and np.array_equal(got, want))}
     except Exception as e:          # secondary figures never fail the bench line
         out["error"] = repr(e)
     # The frames of the headline are already NV21 in HBM.  Where they come from decoded pictures, the colour-conversion / scaling
@@ -865,6 +1019,19 @@ def bench_xacd(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- the dominant kernel, live: HIP events around the speculate launch (adpcm_chunks_kernel<false, ..>) and around the verify
+    #      passes of a few further steps (psxhip_adpcm_session_set_timing: the events are on the session's own stream, inside the call)
+    spec_ms, verify_ms = [], []
+    try:
+        sess.set_timing(True)
+        for _ in range(3):
+            step()
+            a_, b_ = sess.last_timing()
+            spec_ms.append(a_)
+            verify_ms.append(b_)
+        sess.set_timing(False)
+    except Exception:
+        pass
 
     parity = None
     cpu_baseline = None
@@ -882,6 +1049,23 @@ def bench_xacd(args):
         total_sectors = n_sectors * n_ch * args.steps
         value = total_sectors / elapsed
         alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
+        from psxavenc_amd import _lib as _plib
+        try:
+            _plib.lib().psxhip_adpcm_kernel_rev.restype = __import__("ctypes").c_char_p
+            arev = _plib.lib().psxhip_adpcm_kernel_rev().decode()
+        except Exception:
+            arev = "?"
+        xa_key = "xacd kind=%d ch=%d sectors=%d | %s" % (args.audio_kind, n_ch, n_sectors, arev)
+        traffic, traffic_src, pmc = _profile_traffic(xa_key)
+        kroof = None
+        if spec_ms:
+            sm = sorted(spec_ms)[len(spec_ms) // 2]
+            kroof = {"kernel_ms": round(sm, 4), "kernel_ms_all": [round(x, 4) for x in spec_ms], "verify_ms": [round(x, 4) for x in verify_ms],
+                     "achieved": round(alg / (sm * 1e-3) / 1e9, 3), "frac": round(alg / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+            if pmc and pmc.get("valu_insts_per_launch"):
+                slots = 1024 * 2.4e9 / 4.0 * sm * 1e-3
+                kroof["valu_busy_frac"] = round(pmc["valu_insts_per_launch"] / slots, 4)
+                kroof["valu_insts_per_launch"] = pmc["valu_insts_per_launch"]
         print(json.dumps({
             "metric": "xa_37800_4bit_stereo_sectors_per_sec", "value": round(value, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
@@ -891,9 +1075,20 @@ def bench_xacd(args):
                        "preset": args.config, "baseline_config": args.baseline_config,
                        "material": AUDIO_KINDS.get(args.audio_kind, str(args.audio_kind)),
                        "verify_passes_last_step": passes, "chunk_units": chunk_units, "warmup_units": warmup_units, "realtime_factor": round(value * sps / 37800.0 / n_ch, 1)},
-            "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": None, "note": "whole step (sessions incl. host verify loop), not a single kernel"},
+            "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel<false, 12> (speculate: every chunk of every chain from a guessed start state)",
+                         "achieved": kroof["achieved"] if kroof else round(alg * args.steps / elapsed / 1e9, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kroof["frac"] if kroof else round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_key": xa_key,
+                         "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": kroof["kernel_ms"] if kroof else None,
+                         "kernel_ms_method": "HIP events on the session's stream around the speculate launch, 3 steps after the timed region (median)",
+                         "issue": ({"valu_busy_frac": kroof.get("valu_busy_frac"), "valu_insts_per_launch": kroof.get("valu_insts_per_launch"),
+                                    "note": "SQ_INSTS_VALU of the committed PMC pass / (1024 SIMDs x 2.4 GHz / 4 x this run's kernel time): the kernel is a dependent chain per sound unit, bound by VALU issue"} if kroof else None),
+                         "verify_ms": kroof["verify_ms"] if kroof else None,
+                         "per_kernel_counters": (pmc or {}).get("kernels"),
+                         "step": {"achieved": round(alg * args.steps / elapsed / 1e9, 3), "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+                                  "note": "whole step: speculate + verify passes (host-driven) + 8 sector assemblies"},
+                         "note": "algorithmic bytes of the step (PCM in + sectors out) / the speculate kernel's duration: the kernel reads all PCM once and writes 32-byte unit records + 8-byte states (its own traffic: `traffic`)"},
             "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
     sess.close()
     if dist is not None:
@@ -902,73 +1097,135 @@ def bench_xacd(args):
 
 def bench_strcd(args):
     """Config 'strcd v2' (SURVEY 3.2 / 8(d)): 320x240 @15 fps BS v2 + 37800 Hz 4-bit stereo XA muxed into 2352-byte sectors,
-    budgets cycling 16128 / 18144 x3.  A step = one psxhip_str_encode_host call over `--frames` frames per GPU: H2D of the
-    frames and the PCM, one batched MDEC launch + the XA stream on its own stream, D2H, host interleave.  This path hands
-    over HOST buffers, so the rate is PCIe- and host-mux-inclusive (it is a secondary workload; the headline `sbs` line
-    is measured with inputs resident in HBM)."""
+    budgets cycling 16128 / 18144 x3.  A step = one psxhip_str_encode_device call over `--str-streams` independent streams of
+    `--frames` frames per GPU: frames and PCM resident in HBM, sectors land in HBM (the headline's protocol, BASELINE section 4) --
+    one batched MDEC launch over all streams' frames, the streams' XA tracks as chains of one speculate-and-verify session, video
+    sectors built by a kernel, audio sectors assembled into their slots.  The host-buffer entry point (PCIe + host interleave
+    inside the timed region) is measured beside it."""
     import numpy as np
     import torch
     rank, world, local_rank, dev, dist, xdev = _init_dist(args)
-    from psxavenc_amd import strmux, synth
+    from psxavenc_amd import _lib, strmux, synth
     from psxavenc_amd.parallel import shard_range
     w, h, n = 320, 240, args.frames
+    S = max(1, args.str_streams)
     s = strmux.settings(fmt=strmux.FORMAT_STRCD, codec=0, width=w, height=h, fps_num=15, fps_den=1, cd_speed=2)
     first, count = shard_range(n * world, rank, world)
-    frames = synth.frames_device(w, h, args.seed, first, n, args.amp, device=local_rank).cpu().numpy()
     # a little more audio than video, so that the video ends the stream (the reference's loop stops with whichever ends first)
     na = (strmux.plan(s, n).n_audio_sectors + 2) * 2016 + 100
-    pcm = np.zeros(na * 2, np.int16)
-    for c in range(2):
-        pcm[c::2] = synth.pcm_device(args.seed, c, 0, na, 0, device=local_rank).cpu().numpy()[:na]
+    d_frames = torch.stack([synth.frames_device(w, h, args.seed + 17 * i, first, n, args.amp, device=local_rank) for i in range(S)])
+    d_pcm = torch.zeros((S, na * 2), dtype=torch.int16, device=dev)
+    for i in range(S):
+        for c in range(2):
+            synth.pcm_device(args.seed, 2 * i + c, 0, na, args.audio_kind, device=local_rank, out=d_pcm[i][c:], pitch=2)
     p = strmux.plan(s, n, na)
-    sectors = np.zeros((p.n_sectors, p.sector_size), np.uint8)      # the caller's output buffer, reused step after step
+    mux = strmux.StrMuxer((local_rank,))
+    d_out = torch.zeros((S, p.n_sectors, p.sector_size), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
-        strmux.encode(s, frames, pcm, device=local_rank, out=sectors)
+        mux.encode_device(s, d_frames, d_pcm, d_out=d_out)
     _barrier(args, dist, local_rank)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, p2 = strmux.encode(s, frames, pcm, device=local_rank, out=sectors)
+        _, p2 = mux.encode_device(s, d_frames, d_pcm, d_out=d_out)
     _barrier(args, dist, local_rank)
     elapsed_local = time.perf_counter() - t0
-    per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(p.n_sectors * args.steps), float(p2.quant_scale_sum)])
+    per_rank = _gather_ranks(dist, xdev, [elapsed_local, float(p.n_sectors * S * args.steps), float(p2.quant_scale_sum)])
     elapsed = max(r[0] for r in per_rank)
     if rank == 0:
         import hashlib
         import oracle_lib as O
+        # ---- legs (untimed): the video leg alone (the same frames, no audio track), one stream alone, the host-buffer entry point
+        legs = {}
+
+        def timed_dev(settings, fr, pc, reps):
+            o = torch.zeros((fr.shape[0],) + (lambda q: (q.n_sectors, q.sector_size))(strmux.plan(settings, n, na if pc is not None else 0)), dtype=torch.uint8, device=dev)
+            m = strmux.StrMuxer((local_rank,))
+            for _ in range(3):
+                m.encode_device(settings, fr, pc, d_out=o)
+            t = time.perf_counter()
+            for _ in range(reps):
+                m.encode_device(settings, fr, pc, d_out=o)
+            dt = (time.perf_counter() - t) / reps
+            m.close()
+            return dt, o
+        try:
+            s_v = strmux.settings(fmt=strmux.FORMAT_STRCD, codec=0, width=w, height=h, fps_num=15, fps_den=1, cd_speed=2, channels=0)
+            dt_v, _ = timed_dev(s_v, d_frames, None, 20)
+            pv = strmux.plan(s_v, n, 0)
+            legs["video_only_all_sectors_video"] = {"ms_per_step": round(dt_v * 1e3, 4), "sectors_per_sec": round(pv.n_sectors * S / dt_v, 1),
+                                                    "frames_per_sec": round(pv.n_frames_encoded * S / dt_v, 1),
+                                                    "algorithmic_gbs": round(((w * h * 3 // 2) * pv.n_frames_encoded + pv.n_sectors * pv.sector_size) * S / dt_v / 1e9, 2)}
+            dt_1, _ = timed_dev(s, d_frames[:1].contiguous(), d_pcm[:1].contiguous(), 20)
+            legs["one_stream_per_call"] = {"ms_per_step": round(dt_1 * 1e3, 4), "sectors_per_sec": round(p.n_sectors / dt_1, 1),
+                                           "note": "one stream's XA track alone: 2 chains, bound by how far a wrong start state travels (serial re-encode in the verify passes)"}
+        except Exception as e:
+            legs["error"] = repr(e)
+        frames0 = d_frames[0].cpu().numpy()
+        pcm0 = d_pcm[0].cpu().numpy()
+        try:
+            sectors = np.zeros((p.n_sectors, p.sector_size), np.uint8)
+            for _ in range(3):
+                strmux.encode(s, frames0, pcm0, device=local_rank, out=sectors)
+            t = time.perf_counter()
+            reps = 30
+            for _ in range(reps):
+                strmux.encode(s, frames0, pcm0, device=local_rank, out=sectors)
+            dt_h = (time.perf_counter() - t) / reps
+            legs["host_buffers_one_stream"] = {"ms_per_step": round(dt_h * 1e3, 4), "sectors_per_sec": round(p.n_sectors / dt_h, 1),
+                                               "note": "psxhip_str_encode_host: PCIe in and out + host interleave inside the call (round 4's strcd figure)",
+                                               "equals_device_path": bool(np.array_equal(sectors, d_out[0].cpu().numpy()))}
+        except Exception as e:
+            legs["host_buffers_one_stream"] = {"error": repr(e)}
         # parity on a prefix: the reference's sector loop (tests/str_reference_loop.py over the oracle) on the first frames and
-        # their share of the audio -- a complete little stream with its own tail
+        # their share of the audio -- a complete little stream with its own tail -- through the DEVICE path
         import str_reference_loop as R
         k = min(24, n)
-        pk = pcm[:2 * 2016 * 30]
-        sub, _ = strmux.encode(s, frames[:k], pk, device=local_rank)
-        osub, _, _ = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames[:k], pk)
-        parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub, osub))}
+        pk = pcm0[:2 * 2016 * 30]
+        sub, _ = mux.encode_device(s, d_frames[0, :k].contiguous(), torch.from_numpy(pk).to(dev))
+        sub = sub.cpu().numpy()[0]
+        osub, _, _ = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames0[:k], pk)
+        parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub, osub)),
+                  "streams_equal_host_path": legs.get("host_buffers_one_stream", {}).get("equals_device_path")}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
-            c0 = time.perf_counter()
-            done = 0
-            while time.perf_counter() - c0 < args.cpu_seconds:
-                done += R.encode_file_str(7, 0, w, h, 15, 1, 2, frames[:k], pk)[0].shape[0]
-            cpu_baseline = {"value": round(done / (time.perf_counter() - c0), 2), "unit": "sectors/s", "cores": 1, "kind": "port",
-                            "sample": "%d sectors (the reference's sector loop restated over the oracle, first %d frames, repeated)" % (done, k)}
-        total = p.n_sectors * world * args.steps
-        alg = (w * h * 3 // 2) * p2.n_frames_encoded + na * 4 + p.n_sectors * p.sector_size
+            ref = os.path.join(ROOT, "oracle", "_ref", "libpsxav_ref.so")
+            one = _run_cpu_bench(["str", 1, args.cpu_seconds * 0.6, args.seed] + ([ref] if os.path.exists(ref) else []))
+            if one:
+                nthr, cores, cores_note = _usable_cores()
+                cpu_baseline = {"value": one["units_per_sec"], "unit": "sectors/s", "cores": 1, "kind": "port",
+                                "sample": "%d sectors in %.1f s: the sector loop of encode_file_str in C (oracle/cpu_bench.c str: orc_mdec_encode_sector_str + %s, "
+                                          "mode-2 form-1 headers and EDC; gcc -O3)" % (one["units"], one["seconds"], "the reference's own psx_audio_xa_encode" if os.path.exists(ref) else "orc_xa_encode")}
+                many = _run_cpu_bench(["str", nthr, args.cpu_seconds * 0.4, args.seed] + ([ref] if os.path.exists(ref) else []))
+                if many:
+                    cpu_baseline["all_cores"] = {"value": many["units_per_sec"], "unit": "sectors/s", "cores": nthr, "nproc": cores, "cores_note": cores_note,
+                                                 "speedup_vs_1_core": round(many["units_per_sec"] / max(one["units_per_sec"], 1e-9), 1)}
+        total = p.n_sectors * S * world * args.steps
+        alg = ((w * h * 3 // 2) * p2.n_frames_encoded + na * 4 + p.n_sectors * p.sector_size) * S
+        version = _lib.lib().psxhip_version().decode()
         print(json.dumps({
             "metric": "strcd_v2_320x240_sectors_per_sec", "value": round(total / elapsed, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dist": _dist_info(args, dist),
-            "config": {"workload": "strcd v2: %d frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA per GPU per step -> %d sectors of 2352 bytes "
-                                   "(%d video, %d audio); host buffers in and out (PCIe + host interleave inside the timed region)"
-                                   % (n, p.n_sectors, p.n_video_sectors, p.n_audio_sectors),
+            "config": {"workload": "strcd v2: %d independent streams x %d frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA per GPU per step -> %d sectors of 2352 "
+                                   "bytes per stream (%d video, %d audio); frames and PCM resident in HBM, sectors land in HBM (psxhip_str_encode_device)"
+                                   % (S, n, p.n_sectors, p.n_video_sectors, p.n_audio_sectors),
                        "preset": args.config, "baseline_config": args.baseline_config, "tail": "reference (filefmt.c:443-450,492-493)",
-                       "frames_encoded_per_step": p2.n_frames_encoded,
-                       "frames_per_sec": round(p2.n_frames_encoded * world * args.steps / elapsed, 1),
-                       "realtime_factor": round(p2.n_frames_encoded * world * args.steps / elapsed / 15.0, 1),
-                       "avg_quant_scale": round(p2.quant_scale_sum / max(1, p2.n_frames_encoded), 3), "stream_sha256": hashlib.sha256(out.tobytes()).hexdigest()},
-            "roofline": {"bound": "hbm", "kernel": "mdec_encode_frames_kernel", "achieved": round(alg * args.steps / elapsed / 1e9, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                         "note": "whole step incl. PCIe and the host interleave, not a single kernel"},
+                       "streams_per_call": S, "frames_encoded_per_stream": p2.n_frames_encoded,
+                       "frames_per_sec": round(p2.n_frames_encoded * S * world * args.steps / elapsed, 1),
+                       "realtime_factor": round(p2.n_frames_encoded * S * world * args.steps / elapsed / 15.0, 1),
+                       "material": AUDIO_KINDS.get(args.audio_kind, str(args.audio_kind)),
+                       "avg_quant_scale": round(p2.quant_scale_sum / max(1, p2.n_frames_encoded * S), 3),
+                       "stream0_sha256": hashlib.sha256(d_out[0].cpu().numpy().tobytes()).hexdigest(), "library": version, "legs": legs},
+            "roofline": {"bound": "hbm", "kernel": "whole step: mdec_encode_frames_kernel + str_video_sector_kernel beside adpcm_chunks_kernel (speculate, verify) + xa_assemble_kernel",
+                         "achieved": round(alg * args.steps / elapsed / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": None, "traffic_note": "a step is several kernels on two streams; the frame kernel on this budget cycle alone: profiles/pmc_index.json key "
+                                                          "'sbs codec=0 320x240 budget=cycle(16128,18144,18144,18144) ...' (python bench.py --budget-cycle 16128,18144,18144,18144)",
+                         "video_leg_achieved": legs.get("video_only_all_sectors_video", {}).get("algorithmic_gbs"),
+                         "note": "device-resident; the step's time is the XA tracks' verify passes (the tonal test signal), not bytes"},
             "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
+    mux.close()
     if dist is not None:
         dist.destroy_process_group()
 

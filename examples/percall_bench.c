@@ -6,7 +6,9 @@
  * Plain C against libpsxav_hip.so; synthetic input (integer generators); prints one JSON object with the microseconds per call
  * (median and mean over the timed calls).  The bytes themselves are checked by tests/test_gpu_dropin.py and tests/test_gpu_adpcm.py.
  *
- *   ./percall_bench [spu_calls] [xa_calls] [frame_calls]
+ *   ./percall_bench [spu_calls] [xa_calls] [frame_calls] [sweep]
+ * sweep != 0: also psx_audio_spu_encode at 28 .. 114 688 samples per call (state carried), microseconds per call -- where the per-call
+ * drop-in starts to win over the CPU it replaces (the CPU side: oracle/cpu_bench spucall).
  */
 #define _POSIX_C_SOURCE 200809L
 #include <math.h>
@@ -134,6 +136,35 @@ int main(int argc, char **argv) {
 		free(enc.state.frame_output);
 		destroy_mdec_encoder(&enc);
 		free(fr);
+	}
+	if (argc > 4 && atoi(argv[4])) {
+		static const int sizes[] = {28, 56, 112, 224, 448, 896, 1792, 3584, 7168, 14336, 22064, 28672, 57344, 114688};
+		const int ns = (int)(sizeof sizes / sizeof sizes[0]);
+		int16_t *pcm = malloc(sizeof(int16_t) * (size_t)(114688 + 28));
+		uint32_t lcg = 3;
+		for (int i = 0; i < 114688 + 28; i++) {
+			lcg = lcg * 1664525u + 1013904223u;
+			pcm[i] = (int16_t)(9000.0 * sin(i * 0.031) + 4000.0 * sin(i * 0.173) + (int)((lcg >> 20) % 801) - 400);
+		}
+		uint8_t *out = malloc((size_t)(114688 / 28 + 2) * 16);
+		printf(", \"psx_audio_spu_encode_by_samples_per_call\": {");
+		for (int k = 0; k < ns; k++) {
+			const int n = sizes[k], reps = n <= 3584 ? 300 : 60;
+			double *t = malloc(sizeof(double) * (size_t)reps);
+			psx_audio_encoder_channel_state_t st;
+			memset(&st, 0, sizeof st);
+			for (int r = 0; r < reps + 10; r++) {
+				const double a = now_us();
+				psx_audio_spu_encode(&st, pcm, n, 1, out);
+				if (r >= 10) t[r - 10] = now_us() - a;
+			}
+			stats(t, reps, &med, &mean);
+			printf("%s\"%d\": %.2f", k ? ", " : "", n, med);
+			free(t);
+		}
+		printf("}");
+		free(out);
+		free(pcm);
 	}
 	printf(", \"library\": \"%s\"}\n", psxhip_version());
 	return 0;

@@ -409,6 +409,20 @@ int psxhip_str_encode_host(psxhip_str_ctx_t *ctx, const psxhip_str_settings_t *s
                            const int16_t *pcm, int64_t pcm_samples_per_channel, uint8_t *out, size_t out_size,
                            psxhip_str_plan_t *plan);
 
+/* The same, device-resident: frames and PCM in HBM, muxed sectors in HBM -- no PCIe, no host interleave -- for n_streams independent
+ * streams of the same settings and lengths (stream i: frames at d_frames + i * frames_stream_stride bytes, PCM at d_pcm + i *
+ * pcm_stream_stride int16 elements, sectors at d_out + i * out_stream_stride bytes; strides and pointers 4-byte aligned).  The frames
+ * of all streams are one batched MDEC launch, the XA tracks chains of one speculate-and-verify session (S x 2 chains share the
+ * verify passes' latency, which is what bounds ONE stream), the video sectors are built by a kernel (sector header, subheaders,
+ * chunk header mdec.c:782-820, 2016-byte slice :832, form-1 EDC cdrom.c:92-100) and the audio sectors assembled into their slots
+ * (filefmt.c:454-461).  Runs on devices[0] of the handle; `stream` orders the inputs; the call returns when the sectors are complete
+ * (the host drives the verify passes).  Bytes = psxhip_str_encode_host per stream; plan->quant_scale_sum is summed over all streams.
+ * Tables and buffers are kept in the handle for the next call of the same shape. */
+int psxhip_str_encode_device(psxhip_str_ctx_t *ctx, const psxhip_str_settings_t *settings, int n_streams, const uint8_t *d_frames,
+                             size_t frames_stream_stride, int n_frames, const int16_t *d_pcm, int64_t pcm_stream_stride,
+                             int64_t pcm_samples_per_channel, uint8_t *d_out, size_t out_stream_stride, psxhip_str_plan_t *plan,
+                             void *stream);
+
 /* ---------------------------------------------------------------- SPU / VAG / SPUI / VAGI files ---- */
 
 /* The reference's encode_file_spu / encode_file_spui (psxavenc/filefmt.c:212-389, .vag header :95-162) for PCM that is

@@ -212,8 +212,44 @@ static int converge_main(int argc, char **argv) {
 	return 0;
 }
 
+/* cpu_bench spucall <ref.so or -> : microseconds per psx_audio_spu_encode call on ONE core at 28 .. 114 688 samples per call (state
+ * carried): the reference's own function when the path of oracle/_ref's library is given, else orc_spu_encode.  The CPU side of the
+ * per-call break-even; the GPU side is examples/percall_bench's sweep. */
+typedef int (*ref_spu_encode_fn)(ref_chan_t *, const int16_t *, int, int, uint8_t *);
+static int spucall_main(int argc, char **argv) {
+	static const int sizes[] = {28, 56, 112, 224, 448, 896, 1792, 3584, 7168, 14336, 22064, 28672, 57344, 114688};
+	const int ns = (int)(sizeof sizes / sizeof sizes[0]);
+	ref_spu_encode_fn ref = NULL;
+	if (argc > 2 && strcmp(argv[2], "-") != 0) {
+		void *h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
+		if (h) ref = (ref_spu_encode_fn)dlsym(h, "psx_audio_spu_encode");
+	}
+	int16_t *pcm = malloc(sizeof(int16_t) * (size_t)(114688 + 28));
+	orc_synth_pcm(3, 0, 0, 114688 + 28, 0, pcm);
+	uint8_t *out = malloc((size_t)(114688 / 28 + 2) * 16);
+	printf("{\"mode\": \"spucall\", \"kind\": \"%s\", \"us_per_call_by_samples\": {", ref ? "reference" : "port");
+	for (int k = 0; k < ns; k++) {
+		const int n = sizes[k];
+		ref_chan_t rst;
+		orc_adpcm_chan_t ost = {0, 0};
+		memset(&rst, 0, sizeof rst);
+		long calls = 0;
+		const double t0 = now();
+		do {
+			if (ref) (void)ref(&rst, pcm, n, 1, out);
+			else (void)orc_spu_encode(&ost, pcm, n, 1, out);
+			calls++;
+		} while (now() - t0 < 0.25);
+		printf("%s\"%d\": %.3f", k ? ", " : "", n, (now() - t0) * 1e6 / (double)calls);
+	}
+	printf("}}\n");
+	free(pcm); free(out);
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc >= 2 && strcmp(argv[1], "converge") == 0) return converge_main(argc, argv);
+	if (argc >= 2 && strcmp(argv[1], "spucall") == 0) return spucall_main(argc, argv);
 	if (argc < 5) {
 		fprintf(stderr, "usage: cpu_bench mdec <threads> <seconds> <codec> <w> <h> <budget> <amp> <seed>\n"
 		                "       cpu_bench xa <threads> <seconds> <seed> [path to oracle/_ref/libpsxav_ref.so]\n"

@@ -73,6 +73,7 @@ constexpr int kStartedWord = 96;         // groups of this launch that have star
 constexpr int kLeaveWord = 8;
 constexpr int kLeaveWrongShift = 32, kLeaveTriedShift = 48;
 constexpr unsigned kTrustCap = 63u;
+constexpr int kPilotWord = 10;           // (64 bits) what the groups learned about the PILOT's guesses: wrong | tried << 32, added before the group counts itself out
 constexpr int kDistrustWord = 4;         // hint[kDistrustWord]: the launches before this one found foreign hints wrong more than one time in four (shared by the context's lanes, like the hint)
 constexpr int kQueueReservedShift = 32, kQueueHeadShift = 48;
 constexpr unsigned kQueueMask = 0xFFFFu;
@@ -122,6 +123,7 @@ struct FrameJob {
     int retry_patience;      // looks (about 3 us each) a group without work waits for a frame to be handed on
     int retry_cap;
     unsigned prio_pattern;       // [7:0] older group, [15:8] younger group: bit (iteration & 7) = raised priority
+    int trust_mode;              // 0: the trust policy (below); experiments: 1 = foreign hints always trusted (the kernels before mdec-k3.7), 2 = never
     int ck_margin;               // quarter-pass checkpoint: how far (thousandths of its standard error) a projection has to be on the wrong side
     unsigned long long* stats;   // optional [PSXHIP_MDEC_STATS]: pass counters (diagnostics), NULL in normal runs
     uint32_t col_k[16];          // the column pass's sixteen coefficient pairs (col_coeffs()), fetched by ONE scalar load per macroblock
@@ -203,9 +205,11 @@ enum {
     S_HINT_FRAME,       // ... and its index: the hint is the neighbour's answer when that is this frame's index - 1 (inside a run), foreign otherwise
     S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
     S_NEXT_DRAW,        // thread 0's ticket for the run after this one, parked here over the passes (it is a register from the draw to the start of the next frame's passes: the atomic's round trip hides behind a frame's work, and the passes have no register to spare)
-    S_DISTRUST,         // foreign hints are not trusted: frames without a neighbour's answer run the pilot (trust policy, below)
+    S_DISTRUST,         // foreign hints are not trusted: frames without a neighbour's answer run the pilot (trust policy, below): bit 0 the launches before this one found them wrong more than one time in four, bits 8.. this group's foreign hints that failed in a row
     S_F_TRIED,          // foreign hints this group could judge (the frame's answer became known here)
     S_F_WRONG,          // ... and how many of them were not the answer
+    S_P_TRIED,          // frames of this group whose first pass started from the PILOT's guess
+    S_P_WRONG,          // ... and how many of those guesses were not the answer
     S_COUNT
 };
 static_assert((S_SEARCH % 2) == 0, "MdecSearch is read and written as 64-bit pairs");
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const unsigned prio_bits4 = prio_bits * 0x01010101u;      // the pattern four times over: bit (iteration & 31) is bit (iteration & 7)
     if (tid == 0) {
         L.scalars[S_HINT] = 0; L.scalars[S_HINT_BUDGET] = 0; L.scalars[S_HINT_FRAME] = -2; L.scalars[S_SHARED_HINT] = (int)pro_shared_hint;
-        L.scalars[S_DISTRUST] = (int)pro_distrust; L.scalars[S_F_TRIED] = 0; L.scalars[S_F_WRONG] = 0;
+        L.scalars[S_DISTRUST] = (int)pro_distrust; L.scalars[S_F_TRIED] = 0; L.scalars[S_F_WRONG] = 0; L.scalars[S_P_TRIED] = 0; L.scalars[S_P_WRONG] = 0;
         L.scalars[S_PUSHED] = 0; L.scalars[S_QUEUE] = 0; L.scalars[S_NEXT_DRAW] = 0;
     }
     unsigned pass_sum = 0, pass_hist[6] = {0, 0, 0, 0, 0, 0};
@@ -1326,10 +1330,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // run): trusted, the quarter-pass checkpoint catches the scene cuts.  Every other hint is FOREIGN -- the last frame of the
         // group's previous run, a whole round of the grid away, or the previous launch's last answer: right on content that does not
         // change (the uniform synthetic batches), wrong three times in four on scene-structured video (tools/gpu_r05_diag.py: 2.3
-        // passes per frame).  Foreign hints are trusted until they have been wrong: a group that trusted one in vain runs the
-        // pilot on its following run starts (the foreign hint then only tells the pilot where to look first), and goes back to trusting
-        // when a foreign hint would have been right; every group reports what it saw when it leaves, and the launch's verdict
-        // (more than one in four wrong) is where the next launch's groups start from (hint[kDistrustWord]).
+        // passes per frame).  Whether foreign hints are trusted is decided per LAUNCH: every group counts how many of its foreign
+        // hints were (or would have been) the answer and hands the counts in when it leaves; more than one in four wrong, and the
+        // next launch's groups run the pilot on every frame that has no neighbour's answer (the foreign hint then only tells the
+        // pilot where to look first) -- and keep counting, so that the verdict turns back when the content does.  Inside a launch a
+        // group switches on its own only after TWO foreign hints in a row have failed (a change of scene).  One miss says nothing:
+        // on content whose answer flips between two scales (640x480 at 8 KiB, noise +-4: one frame in eight lands on 5 instead of
+        // 6) a pilot after every miss did worse than the hint it replaced -- a dozen macroblocks of 1200 are right 60 % of the time
+        // there, the hint 87 % -- 1.8 M frames/s became 1.2 M.
         int hint = L.scalars[S_HINT];
         int hint_budget = L.scalars[S_HINT_BUDGET];
         bool local = hint >= 1 && L.scalars[S_HINT_FRAME] == f - 1;
@@ -1345,7 +1353,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             local = true;
         }
         const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
-        const bool trust_hint = hint_ok && (local || !L.scalars[S_DISTRUST]);
+        const int dts = L.scalars[S_DISTRUST];
+        const bool distrust = job.trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : job.trust_mode == 2;
+        const bool trust_hint = hint_ok && (local || !distrust);
         if (tid == 0) {
             L.scalars[S_ABORTS_LEFT] = 2;
             L.scalars[S_FOREIGN] = hint_ok && !local ? hint : 0;
@@ -1379,8 +1389,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         for (int i = 0; i < kPilotPerWave; i++) {
             const int pi = wid * kPilotPerWave + i;
             if (pi < n_pilot) {
-                const MbCursor pc = mb_cursor((int)(((unsigned)(2 * pi + 1) * (unsigned)nmb) / (unsigned)(2 * n_pilot)), nx);
-                fetch(pc.fx, pc.fy);
+                // The sample: rows spread evenly, columns by the golden ratio (a Kronecker lattice).  Evenly spaced RASTER indices looked
+                // even and were not: at 640x480 (40 x 30 macroblocks, 12 samples) the stride of 100 lands in two columns only, and a
+                // picture with one busy column -- the synthetic frames' wrap-around edge, a real one's vertical bar -- was estimated
+                // from six macroblocks of it or from none (pilot guesses 2 .. 61 for an answer of 6).
+                const unsigned u = (unsigned)(2 * pi + 1);
+                const int p_fy = (int)((u * (unsigned)ny) / (unsigned)(2 * n_pilot));
+                const int p_fx = (int)((((u * 40503u) >> 1) & 0xFFFFu) * (unsigned)nx >> 16);          // frac((pi + 1/2) * 0.618) * nx
+                fetch(n_pilot == nmb ? pi % nx : p_fx, n_pilot == nmb ? pi / nx : p_fy);
                 {
                     const uint4 ts = L.tab_sel[lane];
                     uint32_t b_lo, b_hi;
@@ -1609,9 +1625,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         // the pass, the pilot was a measurement of its own, and on pictures that are not the same everywhere (a quarter of
                         // the frame full-contrast bars, the rest flat: answer 5, pilot 6, verdict 39) the quarter's rows over-weigh one
                         // part -- such frames took five passes.  The pass runs to its end and the search goes on from what it counted.
+                        // ... unless the projection is on the wrong side by FOUR times the margin: then it is the pilot that was wrong.
                         {
                             const int cur = emit_scale ? emit_scale : count_scale + 1, far = cur > 8 ? cur >> 2 : 2;
-                            if (g && L.scalars[S_PILOTED] && (g - cur >= far || cur - g >= far)) g = 0;
+                            if (g && L.scalars[S_PILOTED] && (g - cur >= far || cur - g >= far))
+                                g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, 4 * margin);
                         }
                         if (g) {
                             L.scalars[S_ABORT] = g | (n_pass << 8);
@@ -2008,10 +2026,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_HINT_BUDGET] = max_size;
                     L.scalars[S_HINT_FRAME] = in_loop(-2);          // (not the neighbour's ANSWER: foreign)
                     L.scalars[S_PUSHED] = 1;
-                    if (L.scalars[S_FOREIGN]) {                     // the frame left with its answer unknown; its foreign hint was not it
+                    if (L.scalars[S_FOREIGN] && !L.scalars[S_PILOTED]) {      // the frame left with its answer unknown; the foreign hint it started from was not it (a frame that started from the pilot's guess says nothing about the hint)
                         L.scalars[S_F_TRIED] = L.scalars[S_F_TRIED] + 1;
                         L.scalars[S_F_WRONG] = L.scalars[S_F_WRONG] + 1;
-                        L.scalars[S_DISTRUST] = 1;
+                        L.scalars[S_DISTRUST] = L.scalars[S_DISTRUST] + 0x100;
                     }
                     return true;
                 };
@@ -2094,12 +2112,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             L.scalars[S_HINT_BUDGET] = max_size;
             L.scalars[S_HINT_FRAME] = f;
             L.scalars[S_PUSHED] = 0;
+            if (L.scalars[S_PILOTED]) {
+                L.scalars[S_P_TRIED] = L.scalars[S_P_TRIED] + 1;
+                L.scalars[S_P_WRONG] = L.scalars[S_P_WRONG] + (guess != scale ? 1 : 0);
+            }
             const int foreign = L.scalars[S_FOREIGN];
             if (foreign) {
                 const int wrong = foreign != scale ? 1 : 0;
                 L.scalars[S_F_TRIED] = L.scalars[S_F_TRIED] + 1;
                 L.scalars[S_F_WRONG] = L.scalars[S_F_WRONG] + wrong;
-                L.scalars[S_DISTRUST] = wrong;
+                const int d0 = L.scalars[S_DISTRUST];
+                L.scalars[S_DISTRUST] = wrong ? d0 + 0x100 : (d0 & 1);
             }
         }
         uint8_t* outp;
@@ -2279,7 +2302,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid == 0) {
             unsigned tried = (unsigned)L.scalars[S_F_TRIED], wrong = (unsigned)L.scalars[S_F_WRONG];
             if (tried > kTrustCap) { wrong = (wrong * kTrustCap + tried / 2) / tried; tried = kTrustCap; }
-            const unsigned long long mine = 1ull | (unsigned long long)wrong << kLeaveWrongShift | (unsigned long long)tried << kLeaveTriedShift;
+            // (the pilot's counts go in first, and the count-out below is made to depend on that atomic's RETURN: whoever sees this
+            //  group gone has its pilot counts in the word too -- no fence)
+            const unsigned long long pr = atomicAdd((unsigned long long*)&job.ticket[kPilotWord],
+                                                    (unsigned long long)(unsigned)L.scalars[S_P_WRONG] | (unsigned long long)(unsigned)L.scalars[S_P_TRIED] << 32);
+            unsigned zero;
+            asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned)pr));
+            const unsigned long long mine = (1ull + zero) | (unsigned long long)wrong << kLeaveWrongShift | (unsigned long long)tried << kLeaveTriedShift;
             const unsigned long long lw = atomicAdd(leave_word(job), mine) + mine;       // groups gone | abandoned queue slots << 16 | wrong << 32 | tried << 48
             lo = (unsigned)lw;
             hi = (unsigned)(lw >> 32);
@@ -2301,8 +2330,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             }
             if (tid == 0) {
                 // the launch's verdict on foreign hints, for the launches after it (a launch that judged fewer than eight leaves it alone)
+                // Foreign hints are distrusted when more than one in four was wrong AND the pilot does better (a launch that ran no
+                // pilots has no say on the second: it goes by the first alone, and the launch after it -- which pilots -- decides
+                // whether that was a good idea: at 640x480 a dozen macroblocks are a poor sample, the pilot is right 60 % of the time
+                // on content whose hints are right 87 %).
                 const unsigned all_wrong = hi & 0xFFFFu, all_tried = hi >> 16;
-                if (all_tried >= 8u) job.hint[kDistrustWord] = 4u * all_wrong > all_tried ? 1u : 0u;
+                const unsigned long long pw = atomicAdd((unsigned long long*)&job.ticket[kPilotWord], 0ull);
+                const unsigned p_wrong = (unsigned)pw, p_tried = (unsigned)(pw >> 32);
+                *(unsigned long long*)&job.ticket[kPilotWord] = 0ull;
+                if (all_tried >= 8u) {
+                    bool distrust_next = 4u * all_wrong > all_tried;
+                    if (distrust_next && p_tried >= 8u && (unsigned long long)p_wrong * all_tried >= (unsigned long long)all_wrong * p_tried) distrust_next = false;
+                    job.hint[kDistrustWord] = distrust_next ? 1u : 0u;
+                }
                 *leave_word(job) = 0ull;
                 job.ticket[kStartedWord] = 0u;
                 *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
@@ -2528,6 +2568,7 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.stats = a->d_stats;
     job.prio_pattern = a->prio_pattern;
     job.ck_margin = a->ck_margin > 0 ? a->ck_margin : 800;
+    job.trust_mode = a->trust_mode;
     { constexpr ColCoeffs ck = col_coeffs(); for (int i = 0; i < 16; i++) job.col_k[i] = ck.k[i]; }
     job.trips = (job.nmb + waves_ - 1) / waves_;
     job.it_step = pick_it_step(job.trips);

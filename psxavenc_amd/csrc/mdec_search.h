@@ -100,9 +100,22 @@ PSX_HD int mdec_search_predict(const MdecSearch& s, int guess, int room, int fix
     float x;      // predicted 1 / scale
     if (s1 && s2 && y1 > y2) {
         const float x1 = 1.0f / (float)s1, x2 = 1.0f / (float)s2;
-        const float b = (float)(y1 - y2) / (x1 - x2);
-        const float a = (float)(y2 - fixed_bits) - b * x2;
-        x = (r - a) / b;
+        float b = (float)(y1 - y2) / (x1 - x2);
+        // Two points on the SAME side of the limit that lie close together say little about the slope when they are projections
+        // from a sample (the pilot, the quarter-pass checkpoint): their difference is mostly noise, and a line that is nearly flat
+        // crosses the limit anywhere (seen: hint 6, both 5 and 6 projected a little too big -> "61"; a frame whose first quarter
+        // over-weighs its busy rows: answer 5 -> "39").  The scale-dependent share of the AC bits is never small -- three quarters
+        // of them and more scale with 1 / scale on everything measured -- so the slope is held to at least a quarter of the
+        // one-point model's (b / scale through the point nearer the limit).  A bracket is interpolated as it is.
+        const bool bracket = s.fs[0] && s.gs[0] && s.fs[0] < s.gs[0];
+        if (!bracket) {
+            const bool fits_only = !s.fs[0];
+            const float xn = fits_only ? x1 : x2, yn = (float)((fits_only ? y1 : y2) - fixed_bits);
+            if (yn > 0.0f && b < 0.25f * yn / xn) b = 0.25f * yn / xn;
+        }
+        float xa = x2, ya = (float)(y2 - fixed_bits);        // the line's anchor: the point nearer the limit
+        if (!bracket && !s.fs[0]) { xa = x1; ya = (float)(y1 - fixed_bits); }
+        x = xa + (r - ya) / b;
     } else {
         const int sa = s2 ? s2 : s1, ya = (s2 ? y2 : y1) - fixed_bits;
         if (ya <= 0) return 1;

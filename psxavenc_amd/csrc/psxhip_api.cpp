@@ -85,6 +85,7 @@ struct psxhip_mdec_ctx {
     hipEvent_t lane_in[2], lane_done[2];
     bool lane_pending[2];           // lane_done[l] has been recorded and no caller stream has been ordered behind it yet
     int retry_patience;
+    int trust_mode;                 // experiments (PSXHIP_MDEC_TRUST): 1 = foreign hints always trusted, 2 = never
     int max_run;                    // longest run of consecutive frames a frame ticket may be (4; PSXHIP_MDEC_RUN: experiments)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
@@ -244,6 +245,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     // content by -2 .. +5 % and cost uniform content 10 % with two launch lanes (groups that finish while their launch's other
     // groups have yet to start may not wait for handed-on frames).  PSXHIP_MDEC_RUN=2 / 4 turns them on.
     c->max_run = 1;
+    if (const char* e = getenv("PSXHIP_MDEC_TRUST")) c->trust_mode = atoi(e);
     if (const char* e = getenv("PSXHIP_MDEC_RUN")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) c->max_run = v; }      // experiments: 1 = single-frame tickets
 
     c->lanes = 1;
@@ -368,6 +370,7 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
     a.d_stats = c->d_stats;
     a.prio_pattern = c->prio_pattern;
     a.ck_margin = c->ck_margin;
+    a.trust_mode = c->trust_mode;
     HIP_TRY(psxhip_mdec_launch(&a), PSXHIP_EDEVICE);
     return PSXHIP_OK;
 }

@@ -22,7 +22,10 @@ namespace {
     } while (0)
 
 // streams at least this long are also split along time (psxhip_adpcm_encode_chains_chunked)
-constexpr int kChunkedThreshold = 4096;
+const int kChunkedThreshold = []() {
+    if (const char* e = getenv("PSXHIP_ADPCM_CHUNK_THRESHOLD")) { const int v = atoi(e); if (v >= 64) return v; }      // experiments
+    return 4096;
+}();
 
 // chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass, and tonal material
 // does not fall into the same state within a thousand units), short enough that there are >= ~8 k chunks -- 1600+

@@ -38,6 +38,7 @@ typedef struct {
 	int retry_patience;             /* looks a group without work waits for a handed-on frame before it leaves */
 	unsigned long long *d_stats;    /* optional [PSXHIP_MDEC_STATS] diagnostics */
 	unsigned prio_pattern;          /* see FrameJob */
+	int trust_mode;                 /* 0 = the trust policy; experiments: 1 = foreign hints always trusted, 2 = never */
 	int ck_margin;                  /* checkpoint margin in thousandths of the projection's standard error (0 = default) */
 	const uint32_t *d_order;        /* psxhip_mdec_pass_table() for this geometry, in device memory */
 } psxhip_mdec_launch_t;

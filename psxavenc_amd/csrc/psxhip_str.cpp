@@ -19,10 +19,28 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/psxav_audio.h"
 #include "../../include/psxav_hip.h"
 #include "../../include/psxav_mdec.h"
 #include "psxhip_internal.h"
+
+namespace {
+struct Sector {
+    int32_t frame;      // >= 0: video sector of that frame; -1: audio sector; -2: audio slot with no samples left
+    int32_t at;         // video: byte offset into the frame's bitstream; audio: index of the XA sector
+    uint8_t eof;        // audio: EOF submode bit (psx_audio_xa_encode_finalize)
+};
+
+struct Plan {
+    psxhip_str_plan_t pub;
+    int base, den;                // frame_block_base_overflow / frame_block_overflow_den, filefmt.c:431-432
+    std::vector<int32_t> budgets; // frame_max_size of every frame in the stream, mdec.c:768-775
+    std::vector<Sector> sectors;
+    int64_t audio_samples;        // per channel, handed to the XA encoder over the whole stream
+};
+}  // namespace
 
 struct psxhip_str_ctx {
     // One multi-device MDEC encoder is kept between calls (creating one allocates pinned staging buffers per device, which
@@ -35,6 +53,26 @@ struct psxhip_str_ctx {
     uint8_t* bs = nullptr;
     size_t bs_cap = 0;
     std::mutex mu;                          // calls on ONE handle are serialised; handles are independent of each other
+    // ---- psxhip_str_encode_device: everything stays in HBM (device devices[0]).  Kept between calls with the same shape: the
+    //      plan's tables on the device, the buffers the frames' bitstreams / unit records pass through, one encoder context, one
+    //      ADPCM session over the caller's PCM, a stream + events for the audio leg
+    struct Dev {
+        psxhip_str_settings_t settings;
+        int n_frames = -1, n_streams = 0;
+        int64_t pcm_samples = -1;
+        const int16_t* d_pcm = nullptr;
+        int64_t pcm_stream_stride = 0;
+        Plan plan;
+        int n_vtab = 0, na = 0, nf = 0;
+        void *d_vtab = nullptr, *d_budgets = nullptr, *d_adst = nullptr, *d_eof = nullptr, *d_bs = nullptr, *d_res = nullptr, *d_units = nullptr;
+        void *d_chains = nullptr, *d_base = nullptr, *d_states = nullptr;      // short audio: the serial chains kernel's tables
+        psxhip_mdec_result_t* h_res = nullptr;                                 // page-locked
+        psxhip_mdec_ctx_t* mdec = nullptr;
+        int mdec_key[4] = {-1, -1, -1, -1};
+        psxhip_adpcm_session_t* session = nullptr;
+        hipStream_t astream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_audio = nullptr;
+    } dev;
 };
 
 namespace {
@@ -68,20 +106,6 @@ bool settings_ok(const psxhip_str_settings_t* s) {
         return false;
     return true;
 }
-
-struct Sector {
-    int32_t frame;      // >= 0: video sector of that frame; -1: audio sector; -2: audio slot with no samples left
-    int32_t at;         // video: byte offset into the frame's bitstream; audio: index of the XA sector
-    uint8_t eof;        // audio: EOF submode bit (psx_audio_xa_encode_finalize)
-};
-
-struct Plan {
-    psxhip_str_plan_t pub;
-    int base, den;                // frame_block_base_overflow / frame_block_overflow_den, filefmt.c:431-432
-    std::vector<int32_t> budgets; // frame_max_size of every frame in the stream, mdec.c:768-775
-    std::vector<Sector> sectors;
-    int64_t audio_samples;        // per channel, handed to the XA encoder over the whole stream
-};
 
 // The sector loop of encode_file_str (filefmt.c:450-503) run dry: which frame slice / audio sector lands in which sector
 // follows from the frame count, the amount of audio and the settings alone.
@@ -201,6 +225,24 @@ int make_plan(const psxhip_str_settings_t* s, int n_frames, int64_t pcm_samples_
 
 }  // namespace
 
+namespace {
+void free_dev(psxhip_str_ctx* c) {
+    psxhip_str_ctx::Dev& d = c->dev;
+    (void)hipSetDevice(c->devices[0]);
+    if (d.astream) (void)hipStreamSynchronize(d.astream);
+    if (d.session) psxhip_adpcm_session_destroy(d.session);
+    if (d.mdec) psxhip_mdec_destroy(d.mdec);
+    void** bufs[] = {&d.d_vtab, &d.d_budgets, &d.d_adst, &d.d_eof, &d.d_bs, &d.d_res, &d.d_units, &d.d_chains, &d.d_base, &d.d_states};
+    for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    if (d.h_res) (void)hipHostFree(d.h_res);
+    if (d.ev_in) (void)hipEventDestroy(d.ev_in);
+    if (d.ev_audio) (void)hipEventDestroy(d.ev_audio);
+    if (d.astream) (void)hipStreamDestroy(d.astream);
+    d.h_res = nullptr; d.ev_in = nullptr; d.ev_audio = nullptr; d.astream = nullptr; d.session = nullptr; d.mdec = nullptr;
+    d.n_frames = -1;
+}
+}  // namespace
+
 extern "C" int psxhip_str_create(psxhip_str_ctx_t** out, const int* devices, int n_devices) {
     if (!out) return PSXHIP_EINVAL;
     *out = nullptr;
@@ -236,6 +278,7 @@ extern "C" void psxhip_str_destroy(psxhip_str_ctx_t* c) {
             (void)hipHostFree(c->bs);
         }
         c->bs = nullptr;
+        free_dev(c);
     }
     delete c;
 }
@@ -475,3 +518,248 @@ extern "C" int psxhip_str_encode_host(psxhip_str_ctx_t* c, const psxhip_str_sett
     if (plan_out) *plan_out = pl.pub;
     return PSXHIP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Device-resident: frames and PCM in HBM -> muxed sectors in HBM.  n_streams independent streams of the same
+// settings and lengths in one call: the frames of all streams are ONE batched MDEC launch (per-frame budgets from the plan),
+// their XA tracks are chains of ONE speculate-and-verify session -- S x 2 chains share the verify passes' latency, which is what
+// bounds a single stream (its one tonal XA track is re-encoded serially for ~3 ms while the frames take 0.2) -- the video sectors
+// are built by a scatter kernel (sector header, subheaders, chunk header, 2016-byte slice, form-1 EDC) and the audio sectors are
+// assembled straight into their slots of the stream.  No PCIe, no host interleave.
+#define DEV_TRY(expr, code)                                                                          \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            psxhip_set_error("psxhip_str_encode_device: %s failed: %s", #expr, hipGetErrorString(e__)); \
+            return (code);                                                                           \
+        }                                                                                            \
+    } while (0)
+
+extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_settings_t* s, int n_streams, const uint8_t* d_frames,
+                                        size_t frames_stream_stride, int n_frames, const int16_t* d_pcm, int64_t pcm_stream_stride,
+                                        int64_t pcm_samples_per_channel, uint8_t* d_out, size_t out_stream_stride,
+                                        psxhip_str_plan_t* plan_out, void* stream) {
+    if (!c || n_streams < 1 || n_streams > 4096) {
+        psxhip_set_error("psxhip_str_encode_device: NULL handle or bad stream count");
+        return PSXHIP_EINVAL;
+    }
+    std::lock_guard<std::mutex> call(c->mu);
+    psxhip_str_ctx::Dev& d = c->dev;
+    const int device = c->devices[0];
+    DEV_TRY(hipSetDevice(device), PSXHIP_EDEVICE);
+    hipStream_t S = (hipStream_t)stream;
+    // ---- the plan and its device tables: rebuilt when the shape of the job changes
+    const bool same = d.n_frames == n_frames && d.pcm_samples == pcm_samples_per_channel && d.n_streams == n_streams && s &&
+                      memcmp(&d.settings, s, sizeof *s) == 0;
+    if (!same) {
+        Plan pl;
+        const int rc = make_plan(s, n_frames, pcm_samples_per_channel, &pl);
+        if (plan_out) *plan_out = pl.pub;
+        if (rc) return rc;
+        // nothing of the old shape may still be running on the buffers that are about to go
+        DEV_TRY(hipStreamSynchronize(S), PSXHIP_EDEVICE);
+        if (d.astream) DEV_TRY(hipStreamSynchronize(d.astream), PSXHIP_EDEVICE);
+        if (d.session) { psxhip_adpcm_session_destroy(d.session); d.session = nullptr; }
+        void** bufs[] = {&d.d_vtab, &d.d_budgets, &d.d_adst, &d.d_eof, &d.d_bs, &d.d_res, &d.d_units, &d.d_chains, &d.d_base, &d.d_states};
+        for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        if (d.h_res) { (void)hipHostFree(d.h_res); d.h_res = nullptr; }
+        d.n_frames = -1;
+        d.plan = pl;
+        d.settings = *s;
+        const int nf = pl.pub.n_frames_encoded, ns = pl.pub.n_sectors;
+        std::vector<int32_t> vtab, adst;
+        std::vector<uint8_t> eof;
+        for (int n = 0; n < ns; n++) {
+            const Sector& sc = pl.sectors[(size_t)n];
+            if (sc.frame == -1) {
+                adst.push_back(n);
+                eof.push_back(sc.eof);
+            } else {
+                vtab.push_back(n);
+                vtab.push_back(sc.frame >= 0 ? sc.frame : -2);
+                vtab.push_back(sc.frame >= 0 ? sc.at : 0);
+                vtab.push_back(sc.frame >= 0 ? pl.budgets[(size_t)sc.frame] : 0);
+            }
+        }
+        d.n_vtab = (int)(vtab.size() / 4);
+        d.na = (int)adst.size();
+        d.nf = nf;
+        const size_t ostride = ((size_t)pl.pub.max_frame_size + 3) & ~(size_t)3;
+        std::vector<int32_t> budgets((size_t)nf * n_streams);
+        for (int i = 0; i < n_streams; i++)
+            for (int f = 0; f < nf; f++) budgets[(size_t)i * nf + f] = pl.budgets[(size_t)f];
+        const int ch = s->audio_channels, upg = s->audio_bit_depth == 4 ? 8 : 4;
+        const size_t units_per_stream = (size_t)d.na * 18 * upg;
+        auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(dst, bytes ? bytes : 4);
+            if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+            return e;
+        };
+        DEV_TRY(up(&d.d_vtab, vtab.data(), vtab.size() * 4), PSXHIP_ENOMEM);
+        DEV_TRY(up(&d.d_budgets, budgets.data(), budgets.size() * 4), PSXHIP_ENOMEM);
+        DEV_TRY(up(&d.d_adst, adst.data(), adst.size() * 4), PSXHIP_ENOMEM);
+        DEV_TRY(up(&d.d_eof, eof.data(), eof.size()), PSXHIP_ENOMEM);
+        const size_t bs_bytes = ostride * (size_t)nf * n_streams + 16;          // (never an empty allocation: a stream may hold no frame at all)
+        DEV_TRY(hipMalloc(&d.d_bs, bs_bytes), PSXHIP_ENOMEM);
+        DEV_TRY(hipMemset(d.d_bs, 0, bs_bytes), PSXHIP_EDEVICE);      // (rows wider than a frame's own budget read as zero there)
+        DEV_TRY(hipMalloc(&d.d_res, sizeof(psxhip_mdec_result_t) * (size_t)(nf ? nf : 1) * n_streams), PSXHIP_ENOMEM);
+        DEV_TRY(hipHostMalloc((void**)&d.h_res, sizeof(psxhip_mdec_result_t) * (size_t)(nf ? nf : 1) * n_streams, hipHostMallocDefault), PSXHIP_ENOMEM);
+        DEV_TRY(hipMalloc(&d.d_units, (units_per_stream ? units_per_stream : 1) * PSXHIP_ADPCM_RECORD_BYTES * n_streams), PSXHIP_ENOMEM);
+        if (!d.astream) DEV_TRY(hipStreamCreateWithFlags(&d.astream, hipStreamNonBlocking), PSXHIP_EDEVICE);
+        if (!d.ev_in) DEV_TRY(hipEventCreateWithFlags(&d.ev_in, hipEventDisableTiming), PSXHIP_EDEVICE);
+        if (!d.ev_audio) DEV_TRY(hipEventCreateWithFlags(&d.ev_audio, hipEventDisableTiming), PSXHIP_EDEVICE);
+        (void)ch;
+        d.n_frames = n_frames;
+        d.pcm_samples = pcm_samples_per_channel;
+        d.n_streams = n_streams;
+        d.d_pcm = nullptr;           // (the ADPCM session is built below, over this call's PCM)
+    }
+    const Plan& pl = d.plan;
+    if (plan_out) *plan_out = pl.pub;
+    const int ns = pl.pub.n_sectors, nf = d.nf, na = d.na;
+    if (ns == 0) return PSXHIP_OK;
+    const size_t ssz = (size_t)pl.pub.sector_size;
+    const size_t fsz = (size_t)s->video_width * s->video_height * 3 / 2;
+    if ((nf && !d_frames) || !d_out || (na && !d_pcm) || out_stream_stride < ssz * (size_t)ns || (out_stream_stride & 3) ||
+        ((uintptr_t)d_out & 3) || (nf && ((frames_stream_stride < fsz * (size_t)n_frames && n_streams > 1) || (frames_stream_stride & 3) || ((uintptr_t)d_frames & 3)))) {
+        psxhip_set_error("psxhip_str_encode_device: NULL / misaligned argument, or a stream stride smaller than a stream");
+        return PSXHIP_EINVAL;
+    }
+    const size_t ostride = ((size_t)pl.pub.max_frame_size + 3) & ~(size_t)3;
+
+    // ---- video: one batched launch over the frames of all streams, then the sector kernel, both on the caller's stream
+    if (nf) {
+        const int key[4] = {s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size};
+        if (!d.mdec || memcmp(key, d.mdec_key, sizeof key) != 0) {
+            if (d.mdec) { psxhip_mdec_destroy(d.mdec); d.mdec = nullptr; }
+            const int rc = psxhip_mdec_create(&d.mdec, device, s->video_codec, s->video_width, s->video_height, pl.pub.max_frame_size);
+            if (rc) return rc;
+            memcpy(d.mdec_key, key, sizeof key);
+        }
+        std::vector<psxhip_mdec_batch_t> batches;
+        const bool contiguous = n_streams == 1 || (frames_stream_stride == fsz * (size_t)nf && nf == n_frames);
+        for (int i = 0; i < (contiguous ? 1 : n_streams); i++) {
+            psxhip_mdec_batch_t b;
+            b.d_frames = d_frames + (size_t)i * frames_stream_stride;
+            b.n_frames = contiguous ? nf * n_streams : nf;
+            b.reserved = 0;
+            b.d_frame_max_sizes = (const int32_t*)d.d_budgets + (size_t)i * nf;
+            b.d_out = (uint8_t*)d.d_bs + (size_t)i * nf * ostride;
+            b.d_results = (psxhip_mdec_result_t*)d.d_res + (size_t)i * nf;
+            batches.push_back(b);
+        }
+        int rc = psxhip_mdec_encode_batches_device(d.mdec, batches.data(), (int)batches.size(), fsz, 0, ostride, S);
+        if (rc) return rc;
+        psxhip_str_video_job_t vj;
+        vj.d_bs = (const uint8_t*)d.d_bs;
+        vj.bs_stride = ostride;
+        vj.bs_stream_stride = ostride * (size_t)nf;
+        vj.d_res = (const psxhip_mdec_result_t*)d.d_res;
+        vj.frames_per_stream = nf;
+        vj.d_tab = (const int32_t*)d.d_vtab;
+        vj.n_entries = d.n_vtab;
+        vj.n_streams = n_streams;
+        vj.format = s->format;
+        vj.sector_size = (int)ssz;
+        vj.xa_file = s->audio_xa_file;
+        vj.xa_channel = s->audio_xa_channel;
+        vj.video_id = s->str_video_id;
+        vj.width = s->video_width;
+        vj.height = s->video_height;
+        vj.d_out = d_out;
+        vj.out_stream_stride = out_stream_stride;
+        rc = psxhip_str_video_sectors_launch(device, &vj, S);
+        if (rc) return rc;
+        DEV_TRY(hipMemcpyAsync(d.h_res, d.d_res, sizeof(psxhip_mdec_result_t) * (size_t)nf * n_streams, hipMemcpyDeviceToHost, S), PSXHIP_EDEVICE);
+    } else if (d.n_vtab) {
+        // no frame in the stream, but audio slots without samples: zero sectors (nothing reads a bitstream)
+        psxhip_str_video_job_t vj;
+        memset(&vj, 0, sizeof vj);
+        vj.d_bs = (const uint8_t*)d.d_bs; vj.d_res = (const psxhip_mdec_result_t*)d.d_res; vj.d_tab = (const int32_t*)d.d_vtab;
+        vj.n_entries = d.n_vtab; vj.n_streams = n_streams; vj.format = s->format; vj.sector_size = (int)ssz; vj.d_out = d_out;
+        vj.out_stream_stride = out_stream_stride;
+        const int rc = psxhip_str_video_sectors_launch(device, &vj, S);
+        if (rc) return rc;
+    }
+
+    // ---- audio: the streams' XA tracks as chains of one session on the handle's own stream, behind the caller's inputs; the
+    //      host drives the verify passes (the call is synchronous), the video leg above runs meanwhile
+    if (na) {
+        const int ch = s->audio_channels, bits = s->audio_bit_depth, upg = bits == 4 ? 8 : 4;
+        const int units_per_stream = na * 18 * upg, units_per_chain = units_per_stream / ch;
+        const int64_t need = pl.audio_samples;                                   // per channel, over the whole stream
+        const int limit = (int)(pcm_samples_per_channel < need ? pcm_samples_per_channel : need);      // past it the encoder reads zeros (decoding.c:521-527)
+        if (n_streams > 1 && pcm_stream_stride < (int64_t)limit * ch) {
+            psxhip_set_error("psxhip_str_encode_device: pcm_stream_stride smaller than a stream's samples");
+            return PSXHIP_EINVAL;
+        }
+        DEV_TRY(hipEventRecord(d.ev_in, S), PSXHIP_EDEVICE);
+        DEV_TRY(hipStreamWaitEvent(d.astream, d.ev_in, 0), PSXHIP_EDEVICE);
+        const int n_chains = n_streams * ch;
+        const bool chunked = units_per_chain >= 4096;
+        if (d.d_pcm != d_pcm || d.pcm_stream_stride != pcm_stream_stride) {
+            if (d.session) { psxhip_adpcm_session_destroy(d.session); d.session = nullptr; }
+            std::vector<psxhip_adpcm_chain_t> chains((size_t)n_chains);
+            std::vector<int32_t> base((size_t)n_chains);
+            for (int i = 0; i < n_streams; i++)
+                for (int k = 0; k < ch; k++) {
+                    psxhip_adpcm_chain_t& cd = chains[(size_t)i * ch + k];
+                    cd.sample_offset = (int64_t)i * pcm_stream_stride + k;
+                    cd.pitch = ch;
+                    cd.sample_limit = limit;
+                    cd.n_units = units_per_chain;
+                    cd.unit_stride = ch;
+                    base[(size_t)i * ch + k] = i * units_per_stream + k;
+                }
+            if (chunked) {
+                int chunk_units = 0, warmup_units = 0;
+                psxhip_adpcm_pick_chunking((long long)units_per_chain * n_chains, 5, device, &chunk_units, &warmup_units);
+                const int rc = psxhip_adpcm_session_create(&d.session, device, d_pcm, chains.data(), base.data(), nullptr, n_chains, 4, bits,
+                                                           (uint8_t*)d.d_units, chunk_units, warmup_units, d.astream);
+                if (rc) return rc;
+            } else {
+                void** bufs[] = {&d.d_chains, &d.d_base, &d.d_states};
+                for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+                DEV_TRY(hipMalloc(&d.d_chains, chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
+                DEV_TRY(hipMalloc(&d.d_base, base.size() * 4), PSXHIP_ENOMEM);
+                DEV_TRY(hipMalloc(&d.d_states, chains.size() * sizeof(psxhip_adpcm_state_t)), PSXHIP_ENOMEM);
+                DEV_TRY(hipMemcpy(d.d_chains, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+                DEV_TRY(hipMemcpy(d.d_base, base.data(), base.size() * 4, hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+            }
+            d.d_pcm = d_pcm;
+            d.pcm_stream_stride = pcm_stream_stride;
+        }
+        int rc;
+        if (chunked) {
+            std::vector<psxhip_adpcm_state_t> zero((size_t)n_chains);
+            memset(zero.data(), 0, zero.size() * sizeof(zero[0]));
+            psxhip_adpcm_session_reset(d.session);
+            rc = psxhip_adpcm_session_run(d.session, zero.data(), nullptr, 0, nullptr, nullptr);
+            if (rc < 0) return rc;
+        } else {
+            DEV_TRY(hipMemsetAsync(d.d_states, 0, (size_t)n_chains * sizeof(psxhip_adpcm_state_t), d.astream), PSXHIP_EDEVICE);
+            rc = psxhip_adpcm_encode_chains_device(device, d_pcm, (const psxhip_adpcm_chain_t*)d.d_chains, (const int32_t*)d.d_base, n_chains, 4,
+                                                   bits, (psxhip_adpcm_state_t*)d.d_states, (uint8_t*)d.d_units, d.astream);
+            if (rc) return rc;
+        }
+        rc = psxhip_xa_assemble_scatter(device, (const uint8_t*)d.d_units, na, s->format == FORMAT_STRCD ? 1 : 0, ch == 2, s->audio_frequency, bits,
+                                        s->audio_xa_file, s->audio_xa_channel, 0, (const uint8_t*)d.d_eof, 0u, d_out, (const int32_t*)d.d_adst,
+                                        n_streams, (size_t)units_per_stream * PSXHIP_ADPCM_RECORD_BYTES, out_stream_stride, d.astream);
+        if (rc) return rc;
+        DEV_TRY(hipEventRecord(d.ev_audio, d.astream), PSXHIP_EDEVICE);
+        DEV_TRY(hipStreamWaitEvent(S, d.ev_audio, 0), PSXHIP_EDEVICE);
+    }
+    DEV_TRY(hipStreamSynchronize(S), PSXHIP_EDEVICE);
+    long long qsum = 0;
+    for (size_t i = 0; i < (size_t)nf * n_streams; i++) {
+        if (d.h_res[i].quant_scale >= 64) {
+            psxhip_set_error("psxhip_str_encode_device: frame %zu of stream %zu does not fit its budget at any quant scale", i % (size_t)nf, i / (size_t)nf);
+            return PSXHIP_ENOFIT;
+        }
+        qsum += d.h_res[i].quant_scale;
+    }
+    if (plan_out) plan_out->quant_scale_sum = qsum;
+    return PSXHIP_OK;
+}
+#undef DEV_TRY

@@ -43,6 +43,8 @@ def _bind():
     L.psxhip_str_destroy.restype = None
     L.psxhip_str_encode_host.argtypes = [C.c_void_p, C.POINTER(StrSettings), C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_size_t, C.POINTER(StrPlan)]
+    L.psxhip_str_encode_device.argtypes = [C.c_void_p, C.POINTER(StrSettings), C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                           C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(StrPlan), C.c_void_p]
     return L
 
 
@@ -118,6 +120,35 @@ class StrMuxer:
                                             per_ch, out.ctypes.data, out.size, C.byref(p))
         _lib.check(rc)
         return out, p
+
+
+    def encode_device(self, s, d_frames, d_pcm=None, d_out=None, stream=None):
+        """psxhip_str_encode_device: everything stays in HBM.  d_frames: uint8 CUDA tensor (S, n_frames, w*h*3/2) (or (n_frames, ..) for
+        one stream); d_pcm: int16 CUDA tensor (S, samples_per_channel * channels), interleaved when stereo, or None.
+        Returns (d_out (S, n_sectors, sector_size) uint8 CUDA tensor, plan); the call returns when the sectors are complete."""
+        import torch
+        if d_frames.dim() == 2:
+            d_frames = d_frames.unsqueeze(0)
+        assert d_frames.is_cuda and d_frames.dtype == torch.uint8 and d_frames.is_contiguous()
+        n_streams, n = d_frames.shape[0], d_frames.shape[1]
+        ch = max(1, s.audio_channels)
+        per_ch = 0
+        if d_pcm is not None:
+            if d_pcm.dim() == 1:
+                d_pcm = d_pcm.unsqueeze(0)
+            assert d_pcm.is_cuda and d_pcm.dtype == torch.int16 and d_pcm.is_contiguous() and d_pcm.shape[0] == n_streams
+            per_ch = d_pcm.shape[1] // ch if s.audio_channels else 0
+        p = plan(s, n, per_ch)
+        if d_out is None:
+            d_out = torch.zeros((n_streams, p.n_sectors, p.sector_size), dtype=torch.uint8, device=d_frames.device)
+        assert d_out.is_cuda and d_out.dtype == torch.uint8 and d_out.is_contiguous() and tuple(d_out.shape) == (n_streams, p.n_sectors, p.sector_size)
+        st = stream if stream is not None else torch.cuda.current_stream(d_frames.device)
+        rc = _bind().psxhip_str_encode_device(self._h, C.byref(s), n_streams, d_frames.data_ptr(), d_frames.stride(0), n,
+                                              d_pcm.data_ptr() if d_pcm is not None and d_pcm.numel() else None,
+                                              d_pcm.stride(0) if d_pcm is not None else 0, per_ch, d_out.data_ptr(),
+                                              d_out.stride(0) if p.n_sectors else 4, C.byref(p), st.cuda_stream)
+        _lib.check(rc)
+        return d_out, p
 
 
 _muxers = {}

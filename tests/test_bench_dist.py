@@ -64,6 +64,32 @@ def test_rccl_leg_at_world_size_1_under_torchrun(preset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("preset", sorted(PRESET_ARGS))
+def test_two_ranks_sharing_the_one_gpu_all_four_presets(preset):
+    """World size 2 on hardware, with real sessions and real contexts (these were kept logs, not tests): two ranks
+    started by bench.py itself through torch.distributed.run, gloo for the exchange (RCCL wants a device per rank), both on GPU 0 --
+    the rank arithmetic (contiguous shares, strong / weak scaling), the gathered per-rank counters, the max-over-ranks time and, for
+    xacd, the time-shard protocol (final states all-gathered, second rank re-verified from its predecessor's truth)."""
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--config", preset, "--steps", "2", "--warmup", "1",
+           "--no-secondary", "--no-cpu-baseline"] + PRESET_ARGS[preset]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode == 0 and line is not None, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "error" not in line, line
+    assert line["n_gpus"] == 2 and line["dist"]["backend"] == "gloo" and line["dist"]["world_size"] == 2
+    assert line["parity"]["bit_exact"] is True and line["value"] > 0
+    if preset in ("sbs_v2", "sbs_v3"):
+        ranks = line["per_rank"]
+        assert [x["rank"] for x in ranks] == [0, 1] and all(x["results_sane"] for x in ranks)
+        if preset == "sbs_v3":          # strong scaling: the job's frames are split
+            assert line["scaling"] == "strong" and line["config"]["frames_per_gpu_per_launch"] == 625
+        else:
+            assert line["scaling"] == "weak" and line["config"]["frames_per_gpu_per_launch"] == 1000
+    if preset == "xacd":
+        assert "time-sharded x2" in line["config"]["workload"]
+
+
+@pytest.mark.gpu
 def test_forced_group_without_torchrun_sets_up_its_own_rendezvous():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1", "--launches-per-step", "8",
                         "--no-secondary", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)

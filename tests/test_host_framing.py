@@ -176,3 +176,20 @@ def test_fdct_pin_kit_still_compiles_against_its_declared_ffmpeg_surface(tmp_pat
                             "-I", os.path.join(ROOT, "oracle"), "-I", os.path.join(ROOT, "include"), src] + extra,
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_pin_fdct_reports_unavailable_in_one_line_without_ffmpeg():
+    """tools/pin_fdct.py is the one command that turns MDEC parity from "unpinned at the FDCT" into "pinned" (README): with an FFmpeg it
+    prints one PASS / FAIL line with the SHA-256 of AVDCT's output vector; in this image (no FFmpeg) it has to say UNAVAILABLE in one
+    line and exit 2 -- not a traceback, and never PASS"""
+    import shutil
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_fdct.py"), "--no-device", "--blocks", "1000"], capture_output=True, text=True)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("PIN_FDCT "), (r.stdout, r.stderr[-500:])
+    have_ffmpeg = any(os.path.exists(os.path.join(d, "libavcodec", "avdct.h")) for d in ("/usr/include", "/usr/local/include", "/usr/include/x86_64-linux-gnu"))
+    if not have_ffmpeg:
+        assert r.returncode == 2 and "UNAVAILABLE" in lines[0]
+    else:
+        assert r.returncode in (0, 1) and "sha256=" in lines[0]

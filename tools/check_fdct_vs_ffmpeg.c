@@ -17,7 +17,7 @@
  *   gcc -O2 -I oracle tools/check_fdct_vs_ffmpeg.c oracle/mdec_oracle.c oracle/mdec_decode.c -lavcodec -lavutil -lm -o check_fdct
  *   gcc -O2 -DWITH_DEVICE -I oracle -I include tools/check_fdct_vs_ffmpeg.c oracle/mdec_oracle.c oracle/mdec_decode.c \
  *       -L psxavenc_amd -lpsxav_hip -Wl,-rpath,$PWD/psxavenc_amd -lavcodec -lavutil -lm -o check_fdct
- * Run:   ./check_fdct [auto|islow] [n_blocks] [seed]
+ * Run:   ./check_fdct [auto|islow] [n_blocks] [seed] [file to write AVDCT's output vector to]      (tools/pin_fdct.py does both)
  * Exit status 0 = every block identical in every comparison.
  */
 #include <libavcodec/avcodec.h>
@@ -99,6 +99,13 @@ int main(int argc, char **argv) {
 	printf("AVDCT.fdct vs oracle restatement (orc_fdct_islow8): %ld of %zu coefficients differ, max |diff| %ld  -> %s\n",
 	       bad_orc, (size_t)n * 64, max_orc, bad_orc ? "NOT PINNED (is this build's fdct ff_jpeg_fdct_islow_8? try `islow`)" : "PINNED");
 	int rc = bad_orc ? 1 : 0;
+	if (argc > 4) {           /* the vector itself, for a hash of what was compared (tools/pin_fdct.py prints its SHA-256) */
+		FILE *fh = fopen(argv[4], "wb");
+		if (fh) {
+			fwrite(ff, sizeof(int16_t), (size_t)n * 64, fh);
+			fclose(fh);
+		}
+	}
 	if (bad_orc) {
 		/* which instance of the IJG butterfly is it then?  (2 extra bits after the row pass = the IJG original, what libjpeg
 		 * ships; 4 = libavcodec's jfdctint_template.c for 8-bit samples, what the oracle assumes) */

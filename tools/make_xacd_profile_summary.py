@@ -43,6 +43,8 @@ def main():
                 e["valu_busy_frac"] = round(e["SQ_INSTS_VALU"] / (1024 * 2.4e9 / 4.0 * e["avg_ns"] * 1e-9), 4)
             kern[role] = e
         key = line["roofline"].get("traffic_key") or ("xacd %s" % tag)
+        if len(sys.argv) > 3 and sys.argv[2].startswith("--key="):
+            pass
         idx[key] = {"source": "profiles/%s_xacd_%s_summary.txt" % (rnd, tag), "kernel": "adpcm_chunks_kernel<false, 12> (speculate)",
                     "traffic_bytes_per_launch": kern["speculate"].get("traffic_bytes_per_launch"),
                     "valu_insts_per_launch": kern["speculate"].get("SQ_INSTS_VALU"), "kernels": kern, "fetch_correction": 2.0,
