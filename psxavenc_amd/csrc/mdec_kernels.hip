@@ -761,8 +761,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nmb = job.nmb, nx = job.nx, ny = job.ny, W = job.width, H = job.height;
     const int nblk = nmb * 6;
-    constexpr int kPilotPerWave = WAVES == kWavesLarge ? 2 : 1;
-    const int n_pilot = nmb < kWavesPerGroup * kPilotPerWave ? nmb : kWavesPerGroup * kPilotPerWave;
+    // the pilot's sample: one macroblock per wavefront, two on frames of 600 macroblocks and more (a dozen of 1200 is 1 %: at 640x480 the
+    // pilot was right 60 % of the time) and in the 16-wavefront shape; macroblock i of the sample belongs to wavefront i % waves
+    constexpr int kPilotPerWave = 2;
+    const int pilot_rounds = (WAVES == kWavesLarge || nmb >= 600) ? 2 : 1;
+    const int n_pilot = nmb < kWavesPerGroup * pilot_rounds ? nmb : kWavesPerGroup * pilot_rounds;
 
     // ---- once per workgroup: LUTs into LDS, per-lane constants.  All global loads are issued before the first result is
     //      waited for: one round trip to the L2 instead of seven in a row (3 us of prologue per group otherwise)
@@ -1387,7 +1390,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         float cfp[kPilotPerWave][6];
 #pragma unroll
         for (int i = 0; i < kPilotPerWave; i++) {
-            const int pi = wid * kPilotPerWave + i;
+            const int pi = wid + i * kWavesPerGroup;
             if (pi < n_pilot) {
                 // The sample: rows spread evenly, columns by the golden ratio (a Kronecker lattice).  Evenly spaced RASTER indices looked
                 // even and were not: at 640x480 (40 x 30 macroblocks, 12 samples) the stride of 100 lands in two columns only, and a
@@ -1438,13 +1441,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             group_sync(1);
             const int np = L.scalars[S_PILOT_N];
             if (np == 0) break;
-            if (wid * kPilotPerWave < n_pilot) {
+            if (wid < n_pilot) {
                 for (int j = 0; j < np; j++) {
                     const int s = L.scalars[S_PILOT_SCALE0 + j];
                     const QuantK k = make_quant(lc.quant, s);
                     int acc = 0;
 #pragma unroll
-                    for (int i = 0; i < kPilotPerWave; i++) acc += count_mb(cfp[i], k, lc, L.ac_len16) & 0xFF;
+                    for (int i = 0; i < kPilotPerWave; i++)
+                        if (i < pilot_rounds) acc += count_mb(cfp[i], k, lc, L.ac_len16) & 0xFF;
                     const int t = wave::reduce_add(acc);
                     if (lane == 0) atomicAdd(&L.scalars[S_PILOT_BITS0 + j], t);
                 }
@@ -2339,7 +2343,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 const unsigned p_wrong = (unsigned)pw, p_tried = (unsigned)(pw >> 32);
                 *(unsigned long long*)&job.ticket[kPilotWord] = 0ull;
                 if (all_tried >= 8u) {
-                    bool distrust_next = 4u * all_wrong > all_tried;
+                    // (without a pilot record the bar is one in THREE: content whose answer flips between two scales one frame in eight
+                    //  has its hints -- the answer of a frame 512 positions back -- wrong 2 x 1/8 x 7/8 = 22 % of the time, and with the
+                    //  bar at 25 % one launch in ten of 640x480 v3 crossed it by chance and was followed by a launch of pilots)
+                    bool distrust_next = p_tried >= 8u ? 4u * all_wrong > all_tried : 3u * all_wrong > all_tried;
                     if (distrust_next && p_tried >= 8u && (unsigned long long)p_wrong * all_tried >= (unsigned long long)all_wrong * p_tried) distrust_next = false;
                     job.hint[kDistrustWord] = distrust_next ? 1u : 0u;
                 }

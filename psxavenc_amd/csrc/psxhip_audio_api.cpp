@@ -26,6 +26,14 @@ const int kChunkedThreshold = []() {
     if (const char* e = getenv("PSXHIP_ADPCM_CHUNK_THRESHOLD")) { const int v = atoi(e); if (v >= 64) return v; }      // experiments
     return 4096;
 }();
+// ... and from 512 units when the call has only a few chains: one chain of 788 blocks (config `spu`'s second of audio) encoded serially
+// by one wavefront takes 1.35 ms, cut along time 0.98 ms; 2048 blocks 3.35 ms against 0.97 (the chunked path's set-up and verify round
+// trips are ~0.75 ms whatever the length, so below ~500 units serial wins; tools/gpu_r05_session_k.sh).  Many short chains keep the
+// serial kernel: it runs them all side by side.
+inline int chunked_threshold(int n_chains) {
+    if (getenv("PSXHIP_ADPCM_CHUNK_THRESHOLD")) return kChunkedThreshold;
+    return n_chains <= 8 ? 512 : kChunkedThreshold;
+}
 
 // chunk length: long enough that verify needs few passes (a wrong guess travels one chunk per pass, and tonal material
 // does not fall into the same state within a thousand units), short enough that there are >= ~8 k chunks -- 1600+
@@ -185,7 +193,7 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     if (rc) return rc;
 
     // ---- the reference's call pattern (a few streams, a few blocks): one launch, no copies (see CallScratch)
-    if (n_streams <= 4 && n_units < kChunkedThreshold && (size_t)n_streams * ((size_t)n_units * 28 + 8) <= (size_t)psxhip_adpcm_call_stage_max() &&
+    if (n_streams <= 4 && n_units < chunked_threshold(n_streams) && (size_t)n_streams * ((size_t)n_units * 28 + 8) <= (size_t)psxhip_adpcm_call_stage_max() &&
         (size_t)n_streams * bytes <= CallScratch::kOut && g_call.ready(device)) {
         psxhip_adpcm_call_t a;
         memset(&a, 0, sizeof a);
@@ -251,7 +259,7 @@ extern "C" int psxhip_spu_encode_streams_host(int device, const int16_t* samples
     HIP_TRY(hipMemcpyAsync(d_c.p, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_st.p, states, n_streams * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
-    if (n_units >= kChunkedThreshold) {
+    if (n_units >= chunked_threshold(n_streams)) {
         // long streams: parallel along time as well (speculate-and-verify; same bytes as the serial chain kernel)
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
         int chunk_units, warmup_units;
@@ -389,7 +397,7 @@ extern "C" int psxhip_xa_encode_streams_host_flags(int device, int format, int s
     HIP_TRY(hipMemcpyAsync(d_b.p, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_st.p, states, chains.size() * sizeof(psxhip_adpcm_state_t), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
     HIP_TRY(hipMemcpyAsync(d_e.p, eof.data(), eof.size(), hipMemcpyHostToDevice, st), PSXHIP_EDEVICE);
-    if (units_per_chain >= kChunkedThreshold) {
+    if (units_per_chain >= chunked_threshold((int)chains.size())) {
         HIP_TRY(hipStreamSynchronize(st), PSXHIP_EDEVICE);
         int chunk_units, warmup_units;
         pick_chunking((long long)units_per_chain * (long long)chains.size(), 5, device, &chunk_units, &warmup_units);

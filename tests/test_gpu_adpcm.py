@@ -547,3 +547,25 @@ def test_per_call_path_speculates_inside_one_launch_and_equals_the_serial_encode
         assert (st.left.prev1, st.left.prev2) == (ost.left.prev1, ost.left.prev2)
         if stereo:
             assert (st.right.prev1, st.right.prev2) == (ost.right.prev1, ost.right.prev2)
+
+
+def test_mid_size_single_streams_take_the_chunked_path_and_match():
+    """round 5: a call with few chains cuts them along time from 512 units on (a lone chain encoded serially runs at one wavefront's
+    pace); lengths either side of the switch, SPU and XA, every signal class, state carried in and out"""
+    from psxavenc_amd import adpcm
+    for kind in (0, 2, 4, 5):
+        for n_units in (500, 511, 512, 513, 788, 1500):
+            n = 28 * n_units - (5 if n_units % 2 else 0)
+            pcm = O.synth_pcm(61, kind, 0, n, kind).reshape(1, -1)
+            st = np.array([[123, -77]], np.int32)
+            out = adpcm.spu_encode_streams(pcm, states=st.copy())
+            want, wst = O.spu_encode(pcm[0], state=O.Chan(123, -77))
+            assert np.array_equal(out[0], want), (kind, n_units)
+    s = adpcm.XaSettings(1, True, 37800, 4, 1, 0)
+    for sectors in (7, 8, 20):
+        ns = 2016 * sectors - 300
+        x = stereo_pad(5, ns, 3, pad=4032)
+        got = adpcm.xa_encode_streams(s, x.reshape(1, -1), ns, lbas=[11])[0]
+        os_ = O.XaSettings(1, 1, 37800, 4, 1, 0)
+        want, _ = O.xa_encode(os_, x, ns, lba=11)
+        assert np.array_equal(got, want), sectors
