@@ -1632,8 +1632,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         // ... unless the projection is on the wrong side by FOUR times the margin: then it is the pilot that was wrong.
                         {
                             const int cur = emit_scale ? emit_scale : count_scale + 1, far = cur > 8 ? cur >> 2 : 2;
-                            if (g && L.scalars[S_PILOTED] && (g - cur >= far || cur - g >= far))
-                                g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, 4 * margin);
+                            if (g && L.scalars[S_PILOTED] && (g - cur >= far || cur - g >= far)) {
+                                // (the test of mdec_search_checkpoint_bits with four times the margin; the new guess stays the one just made)
+                                const bool too_low = emit_scale && pb > (long long)limit_bits + 4 * margin;
+                                const bool too_high = count_scale && pa <= (long long)limit_bits - 4 * margin;
+                                if (!too_low && !too_high) g = 0;
+                            }
                         }
                         if (g) {
                             L.scalars[S_ABORT] = g | (n_pass << 8);
@@ -2308,10 +2312,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (tried > kTrustCap) { wrong = (wrong * kTrustCap + tried / 2) / tried; tried = kTrustCap; }
             // (the pilot's counts go in first, and the count-out below is made to depend on that atomic's RETURN: whoever sees this
             //  group gone has its pilot counts in the word too -- no fence)
-            const unsigned long long pr = atomicAdd((unsigned long long*)&job.ticket[kPilotWord],
-                                                    (unsigned long long)(unsigned)L.scalars[S_P_WRONG] | (unsigned long long)(unsigned)L.scalars[S_P_TRIED] << 32);
-            unsigned zero;
-            asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned)pr));
+            // (a group that ran no pilot -- every group of a launch on content whose hints hold -- has nothing to hand in and does not
+            //  pay the atomic's round trip on its way out: 2 us at the end of a 127 us launch)
+            unsigned zero = 0;
+            if (L.scalars[S_P_TRIED]) {
+                const unsigned long long pr = atomicAdd((unsigned long long*)&job.ticket[kPilotWord],
+                                                        (unsigned long long)(unsigned)L.scalars[S_P_WRONG] | (unsigned long long)(unsigned)L.scalars[S_P_TRIED] << 32);
+                asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned)pr));
+            }
             const unsigned long long mine = (1ull + zero) | (unsigned long long)wrong << kLeaveWrongShift | (unsigned long long)tried << kLeaveTriedShift;
             const unsigned long long lw = atomicAdd(leave_word(job), mine) + mine;       // groups gone | abandoned queue slots << 16 | wrong << 32 | tried << 48
             lo = (unsigned)lw;
@@ -2339,17 +2347,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // whether that was a good idea: at 640x480 a dozen macroblocks are a poor sample, the pilot is right 60 % of the time
                 // on content whose hints are right 87 %).
                 const unsigned all_wrong = hi & 0xFFFFu, all_tried = hi >> 16;
-                const unsigned long long pw = atomicAdd((unsigned long long*)&job.ticket[kPilotWord], 0ull);
-                const unsigned p_wrong = (unsigned)pw, p_tried = (unsigned)(pw >> 32);
-                *(unsigned long long*)&job.ticket[kPilotWord] = 0ull;
                 if (all_tried >= 8u) {
                     // (without a pilot record the bar is one in THREE: content whose answer flips between two scales one frame in eight
                     //  has its hints -- the answer of a frame 512 positions back -- wrong 2 x 1/8 x 7/8 = 22 % of the time, and with the
                     //  bar at 25 % one launch in ten of 640x480 v3 crossed it by chance and was followed by a launch of pilots)
-                    bool distrust_next = p_tried >= 8u ? 4u * all_wrong > all_tried : 3u * all_wrong > all_tried;
-                    if (distrust_next && p_tried >= 8u && (unsigned long long)p_wrong * all_tried >= (unsigned long long)all_wrong * p_tried) distrust_next = false;
+                    bool distrust_next = false;
+                    if (4u * all_wrong > all_tried) {          // (only then is the pilot's record looked at: a round trip at the very end of the launch)
+                        const unsigned long long pw = atomicAdd((unsigned long long*)&job.ticket[kPilotWord], 0ull);
+                        const unsigned p_wrong = (unsigned)pw, p_tried = (unsigned)(pw >> 32);
+                        distrust_next = p_tried >= 8u ? (unsigned long long)p_wrong * all_tried < (unsigned long long)all_wrong * p_tried : 3u * all_wrong > all_tried;
+                    }
                     job.hint[kDistrustWord] = distrust_next ? 1u : 0u;
                 }
+                *(unsigned long long*)&job.ticket[kPilotWord] = 0ull;
                 *leave_word(job) = 0ull;
                 job.ticket[kStartedWord] = 0u;
                 *queue_state(job) = 0ull;       // tickets and queue counters (every slot that was filled has been vacated by the group that took it)
