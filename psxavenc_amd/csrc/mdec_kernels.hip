@@ -187,9 +187,9 @@ enum {
     S_ABORT,            // checkpoint verdict: new guess | pass number << 8 (a verdict of an earlier pass is stale, not reset)
     S_ABORTS_LEFT,      // checkpoints still allowed for this frame
     S_RETRY,            // this frame came from the retry queue: the scale to start from (0: a fresh frame; -1: the queue is empty)
-    S_DEFER,            // the frame goes to the retry queue instead of into another pass here
+    S_DEFER,            // 1: the frame goes to the retry queue instead of into another pass here; 2: it starts over from the pilot (S_REPILOT)
     S_PILOTED,          // the pilot has run for this frame (its guess is a measurement, not somebody else's answer)
-    S_REPILOT,          // the first pass, started from a hint, was stopped with a verdict FAR from the hint (a scene cut): the verdict; the frame starts over from the pilot
+    S_SPARE0,           // (unused)
     S_SEARCH,           // MdecSearch (14 ints)
     S_PILOT_SCALE0 = S_SEARCH + 14,    // [kPilotMax]
     S_PILOT_BITS0 = S_PILOT_SCALE0 + kPilotMax,   // [kPilotMax]
@@ -205,6 +205,7 @@ enum {
     S_HINT_FRAME,       // ... and its index: the hint is the neighbour's answer when that is this frame's index - 1 (inside a run), foreign otherwise
     S_SHARED_HINT,      // answer | budget << 8 of the previous launch's last frame (by index)
     S_NEXT_DRAW,        // thread 0's ticket for the run after this one, parked here over the passes (it is a register from the draw to the start of the next frame's passes: the atomic's round trip hides behind a frame's work, and the passes have no register to spare)
+    S_REPILOT,          // the first pass, started from a hint, was stopped with a verdict FAR from the hint (a scene cut): the verdict.  The frame starts over from the pilot: one more turn of the frame loop for the same frame (taken back to 0 once the pilot has read it)
     S_DISTRUST,         // foreign hints are not trusted: frames without a neighbour's answer run the pilot (trust policy, below): bit 0 the launches before this one found them wrong more than one time in four, bits 8.. this group's foreign hints that failed in a row
     S_F_TRIED,          // foreign hints this group could judge (the frame's answer became known here)
     S_F_WRONG,          // ... and how many of them were not the answer
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     if (tid == 0) {
         L.scalars[S_HINT] = 0; L.scalars[S_HINT_BUDGET] = 0; L.scalars[S_HINT_FRAME] = -2; L.scalars[S_SHARED_HINT] = (int)pro_shared_hint;
         L.scalars[S_DISTRUST] = (int)pro_distrust; L.scalars[S_F_TRIED] = 0; L.scalars[S_F_WRONG] = 0; L.scalars[S_P_TRIED] = 0; L.scalars[S_P_WRONG] = 0;
-        L.scalars[S_PUSHED] = 0; L.scalars[S_QUEUE] = 0; L.scalars[S_NEXT_DRAW] = 0;
+        L.scalars[S_PUSHED] = 0; L.scalars[S_QUEUE] = 0; L.scalars[S_NEXT_DRAW] = 0; L.scalars[S_REPILOT] = 0;
     }
     unsigned pass_sum = 0, pass_hist[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_start = 0, t_mark = 0, phase_ticks[6] = {0, 0, 0, 0, 0, 0};
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     // answer is known.
     const bool scan_early = nmb <= 512;
     int n_done = 0;
+    int carry_pass = 0, carry_guess0 = 0, carry_abort = 0;      // diagnostics: passes and first guess of a frame's first attempt (a frame sent back to the pilot)
     if (STATS) t_start = t_mark = wall_clock64();
     // thread 0: the ticket for the frame after next, drawn one frame ahead and kept AS DRAWN (ticket - gridDim.x): nothing is computed
     // from it before the next frame's decisions, so the atomic's round trip hides behind a frame's work (adding gridDim.x -- a
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         asm volatile("" : "+v"(tid_f));
         const int tid = tid_f;               // shadows the kernel-scope copy on purpose
         int f = L.scalars[S_FIDX];
-        if (L.scalars[S_FRAME] >= job.n_tickets) {
+        if (L.scalars[S_FRAME] >= job.n_tickets && !L.scalars[S_REPILOT]) {      // (S_REPILOT: the frame in hand -- one taken from the queue -- starts over)
             // No fresh frame left for this group: frames that other groups handed on instead of running another pass over them
             // (see the end of the pass loop).  Everything here goes through read-modify-write atomics -- the queue is shared by
             // groups on all XCDs, whose L2s are not coherent for plain loads.  A group leaves when it finds the queue empty;
@@ -1357,10 +1359,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
         const int dts = L.scalars[S_DISTRUST];
+        const int rp = L.scalars[S_REPILOT];     // this frame is being started over from the pilot (below): the verdict that sent it back
         const bool distrust = job.trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : job.trust_mode == 2;
-        const bool trust_hint = hint_ok && (local || !distrust);
+        const bool trust_hint = hint_ok && (local || !distrust) && rp == 0;
         if (tid == 0) {
-            L.scalars[S_ABORTS_LEFT] = 2;
+            L.scalars[S_ABORTS_LEFT] = rp ? 1 : 2;          // (a frame sent back to the pilot has used one)
             L.scalars[S_FOREIGN] = hint_ok && !local ? hint : 0;
         }
         // A frame started from a hint (no pilot) whose first pass is stopped with a verdict FAR from the hint -- a scene cut: the
@@ -1378,12 +1381,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 st.gs[0] = st.gs[1] = st.gb[0] = st.gb[1] = z;
             }
         };
-        bool repilot = false;
+        unsigned long long trace = 0;       // diagnostics: the first four passes (of the last attempt): emit scale, or count scale | 0x40; | 0x80 stopped at the checkpoint
         int n_pass = 0, first_abort = 0, guess0 = 0;      // (first_abort, guess0: diagnostics)
         int guess;
         MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
-        for (;;) {
-        if (trust_hint && !repilot) {
+        if (trust_hint) {
             if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
             group_sync(1);
         } else {
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         if (tid == 0) {
             L.scalars[S_PILOTED] = 1;
             int h0 = hint_budget == max_size ? hint : 0;        // (not trusted, or for another budget: it still says where to look first)
-            if (repilot) h0 = L.scalars[S_REPILOT];
+            if (rp) h0 = rp;
             if (h0 < 1) {
                 // no frame of its own yet: another group's last answer for the same budget is a good place to start looking
                 const int sh = L.scalars[S_SHARED_HINT];
@@ -1475,13 +1477,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         }
         guess = L.scalars[S_PILOT_GUESS];
-        if (STATS && !repilot) guess0 = guess;
+        if (STATS) { guess0 = rp ? carry_guess0 : guess; if (rp) first_abort = carry_abort; }
         mark(2);   // pilot
 
         // ---- exact search (mdec_search.h): the state lives in LDS, thread 0 advances it between passes; every pass is
         //      described by two scalars
         if (tid == 0) {
             L.scalars[S_NEXT_DRAW] = (int)next_draw;
+            if (rp) L.scalars[S_REPILOT] = in_loop(0);          // (everybody read it before the barrier above)
             MdecSearch st;
             search_reset(st);
             MdecPass np;
@@ -1502,6 +1505,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         while (!L.scalars[S_DONE]) {
             const int count_scale = L.scalars[S_PASS_COUNT], emit_scale = L.scalars[S_PASS_EMIT];
             n_pass++;
+            if (STATS && n_pass <= 4) trace |= (unsigned long long)(emit_scale ? emit_scale : count_scale | 0x40) << (24 + 8 * n_pass);
             if (emit_scale && n_pass > 1) {
                 // a further emitting pass rebuilds the staging area
                 for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
@@ -2005,6 +2009,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             const int verdict = L.scalars[S_ABORT];
             aborted = (verdict >> 8) == n_pass;          // (this pass's verdict; an older one is stale)
             if (STATS && tid == 0 && aborted && !first_abort) first_abort = verdict & 0xFF;
+            if (STATS && aborted && n_pass <= 4) trace |= 0x80ull << (24 + 8 * n_pass);
             if (scan_early && wid == 1 && emit_scale && !aborted) scan_offsets(lane);
             if (tid == 0) {
                 MdecSearch st = *srch;
@@ -2055,6 +2060,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     const int vg = verdict & 0xFF, far = guess > 8 ? guess >> 2 : 2;
                     if (n_pass == 1 && !L.scalars[S_PILOTED] && !np.done && (vg - guess >= far || guess - vg >= far)) {
                         L.scalars[S_REPILOT] = vg;
+                        L.scalars[S_DEFER] = 2;
                         L.scalars[S_DONE] = 1;          // leaves the pass loop; the frame starts over from the pilot (below)
                     } else {
                         (void)hand_on(np);
@@ -2087,22 +2093,32 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (kStopAfter && tid == 0) L.scalars[S_DONE] = 1;
             group_sync(4);
         }
-        if (repilot || !L.scalars[S_REPILOT]) break;
-        repilot = true;
-        group_sync(4);          // (everybody has seen S_REPILOT and S_DONE; the pilot and the search start-up write the scalars again)
-        }
-        n_done++;
         mark(3);   // passes
-        if (L.scalars[S_DEFER]) {
+        const int defer = L.scalars[S_DEFER];
+        if (defer) {
             // handed on: nothing of this frame is written here
             group_sync(5);      // everyone has read the verdict: the scalars may go
-            end_of_frame(tid);
+            if (defer == 2) {
+                // ... or sent back to the pilot: the frame loop's next turn is the same frame again, with the per-frame state as a
+                // fresh frame finds it and the ticket state untouched.  (A turn of the frame loop, not a loop around the pilot and
+                // the passes: that loop cost EVERY frame 1.5 % -- values of the frame's start kept alive across the passes, in a
+                // kernel that has no register to spare -- for the one frame in fifteen that takes it.)
+                for (int i = tid; i < job.stg_words; i += kThreads) L.stg[i] = 0u;
+                if (tid < S_KEEP0 && tid != S_RETRY) L.scalars[tid] = 0;       // (a frame taken from the retry queue stays one: it is not handed on again)
+                if (tid == 0) next_draw = (unsigned)L.scalars[S_NEXT_DRAW];
+                if (STATS) { carry_pass += n_pass; carry_guess0 = guess0; carry_abort = first_abort; }
+            } else {
+                n_done++;
+                end_of_frame(tid);
+            }
             group_sync(5);
             continue;
         }
+        n_done++;
+        if (STATS) { n_pass += carry_pass; carry_pass = 0; }      // (a frame sent back to the pilot: its first attempt's pass counts)
         if (STATS && tid == 0 && f < PSXHIP_MDEC_TRACE_FRAMES)      // per-frame record: first guess | first abort verdict << 8 | answer << 16 | passes << 24
             job.stats[PSXHIP_MDEC_STATS_FRAME0 + f] = (unsigned long long)(guess0 & 0xFF) | (unsigned long long)(first_abort & 0xFF) << 8 |
-                                                      (unsigned long long)(L.scalars[S_RESULT] & 0xFF) << 16 | (unsigned long long)n_pass << 24;
+                                                      (unsigned long long)(L.scalars[S_RESULT] & 0xFF) << 16 | (unsigned long long)(n_pass & 0xFF) << 24 | trace;
         if (STATS && tid == 0) {
             pass_sum += (unsigned)n_pass;
             for (int c = 0; c < 6; c++) pass_hist[c] += (n_pass > 5 ? 5 : n_pass) == c ? 1u : 0u;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on ONE box (box-to-box spread is about 1.5 %, more than a kernel revision's fixed costs):
 one process per (library, round), alternating; each prints the in-order and two-lane time per 1000-frame launch of the content
-class.  usage: python tools/gpu_ab_rates.py <libA.so> <libB.so> [kind ...] [--rounds 3] [--json out.json]
+class.  usage: python tools/gpu_ab_rates.py <libA.so> <libB.so> [more.so ...] [kind ...] [--rounds 3] [--json out.json]
 (child: PSXAV_HIP_LIB=<lib> python tools/gpu_ab_rates.py --child kind)"""
 import json
 import os
@@ -44,7 +44,8 @@ def main():
         i = argv.index("--rounds"); rounds = int(argv[i + 1]); del argv[i:i + 2]
     if "--json" in argv:
         i = argv.index("--json"); json_out = argv[i + 1]; del argv[i:i + 2]
-    libs, kinds = [os.path.abspath(argv[0]), os.path.abspath(argv[1])], argv[2:] or ["a4"]
+    libs = [os.path.abspath(a) for a in argv if a.endswith(".so")]
+    kinds = [a for a in argv if not a.endswith(".so")] or ["a4"]
     res = {}
     for kind in kinds:
         for rnd in range(rounds):

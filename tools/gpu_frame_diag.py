@@ -16,7 +16,7 @@ NT = 8 + 4 * 1024 + 16 + 2048
 t = (C.c_ulonglong * NT)()
 _lib.lib().psxhip_mdec_read_stats(enc._h, t, NT, 0)
 fr = np.array(list(t)[8 + 4096 + 16:8 + 4096 + 16 + n], dtype=np.int64)
-guess, ab, ans, np_ = fr & 0xFF, (fr >> 8) & 0xFF, (fr >> 16) & 0xFF, fr >> 24
+guess, ab, ans, np_ = fr & 0xFF, (fr >> 8) & 0xFF, (fr >> 16) & 0xFF, (fr >> 24) & 0xFF
 import collections
 c = collections.Counter(zip(guess.tolist(), ab.tolist(), ans.tolist(), np_.tolist()))
 for k, v in sorted(c.items(), key=lambda x: -x[1])[:14]: print("guess %d abort->%d answer %d passes %d : %d frames" % (k + (v,)))

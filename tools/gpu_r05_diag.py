@@ -111,7 +111,8 @@ def stats_run(bb, warm):
     enc.close()
     r = {"frames": s[0], "passes_per_frame": round(s[1] / max(1, s[0]), 4), "passes_hist_0_1_2_3_4_5plus": s[2:8]}
     fr = np.array(s[8 + 4096 + 16:8 + 4096 + 16 + N], dtype=np.int64)
-    guess, ab, ans, np_ = fr & 0xFF, (fr >> 8) & 0xFF, (fr >> 16) & 0xFF, fr >> 24
+    guess, ab, ans, np_ = fr & 0xFF, (fr >> 8) & 0xFF, (fr >> 16) & 0xFF, (fr >> 24) & 0xFF
+    tr = ["/".join(("%d%s%s" % (b & 0x3F, "c" if b & 0x40 else "", "!" if b & 0x80 else "")) for b in [(int(x) >> (32 + 8 * k)) & 0xFF for k in range(4)] if b) for x in fr]
     r["first_guess_right"] = int((guess == ans).sum())
     r["first_guess_off_by_one"] = int((np.abs(guess - ans) == 1).sum())
     r["first_guess_off_by_more"] = int((np.abs(guess - ans) > 1).sum())
@@ -119,6 +120,8 @@ def stats_run(bb, warm):
     c = collections.Counter(zip(guess.tolist(), ab.tolist(), ans.tolist(), np_.tolist()))
     r["top_cases_guess_abort_answer_passes_count"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[1])[:10]]
     r["cases_with_3_or_more_passes"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[0][3] * 1000 - x[1]) if k[3] >= 3][:16]
+    c2 = collections.Counter(zip(guess.tolist(), ab.tolist(), ans.tolist(), np_.tolist(), tr))
+    r["pass_traces_of_frames_with_3_or_more_passes"] = [list(k) + [v] for k, v in sorted(c2.items(), key=lambda x: -x[0][3] * 1000 - x[1]) if k[3] >= 3][:24]
     ph = np.array(s[8 + 4096:8 + 4096 + 16], dtype=np.float64)
     r["phase_share_pct_ticket_resetdc_pilot_passes_scanmerge_writeout"] = np.round(100 * ph[:6] / max(1.0, ph[:6].sum()), 1).tolist()
     r["barrier_wait_pct_of_residency"] = round(100.0 * ph[6] / max(1.0, ph[7]), 1)
