@@ -73,6 +73,7 @@ constexpr int kStartedWord = 96;         // groups of this launch that have star
 constexpr int kLeaveWord = 8;
 constexpr int kLeaveWrongShift = 32, kLeaveTriedShift = 48;
 constexpr unsigned kTrustCap = 63u;
+constexpr int kNoTicket = 0x7FFFFFFF;   // S_FRAME of a group that holds no fresh-frame ticket (any more): it takes frames from the retry queue
 constexpr int kPilotWord = 10;           // (64 bits) what the groups learned about the PILOT's guesses: wrong | tried << 32, added before the group counts itself out
 constexpr int kDistrustWord = 4;         // hint[kDistrustWord]: the launches before this one found foreign hints wrong more than one time in four (shared by the context's lanes, like the hint)
 constexpr int kQueueReservedShift = 32, kQueueHeadShift = 48;
@@ -139,6 +140,12 @@ __device__ __forceinline__ BatchPtr batch_table() {
     asm volatile("" : "+s"(p));
     return p;
 }
+// An int member of the kernel argument, loaded where it is asked for (a scalar load from the argument segment): as plain members
+// the arguments the frame loop reads now and then -- the ticket plan, the trust mode, the queue's patience -- are loaded at kernel
+// entry and kept, one scalar register each for the whole kernel, in a kernel that spills a hundred of them: mdec-k3.7's four new
+// ones pushed the frame pointer of the macroblock loop out of its scalar pair (two v_readfirstlane and a v_readlane more per
+// macroblock: +1.5 % vector instructions, found with the instruction counters of tools/gpu_r05_session_p.sh).
+#define PSX_JOB_INT(member) (((FirstPtr)((const char __attribute__((address_space(4)))*)batch_table() + offsetof(FrameJob, member)))[0])
 // the retry queue's slots, the address made where it is used (one thread, rarely): as a loop invariant the 64-bit address sat in
 // two vector registers -- or a scratch slot -- for the whole kernel
 __device__ __forceinline__ unsigned int* retry_slots(const FrameJob& job) {
@@ -156,10 +163,10 @@ __device__ __forceinline__ unsigned long long* leave_word(const FrameJob& job) {
 // grid back -- 512 frames: another scene.  Long runs first, short ones at the end (the host sizes t4 / t2 so that every round of
 // the grid is whole, psxhip_mdec_launch): guided self-scheduling, the tail of a launch is still balanced frame by frame.
 __device__ __forceinline__ void ticket_run(const FrameJob& job, int t, int& first, int& len) {
-    const int t4 = job.t4, t42 = job.t4 + job.t2;
+    const int t4 = PSX_JOB_INT(t4), t2 = PSX_JOB_INT(t2), t42 = t4 + t2;
     if (t < t4) { first = 4 * t; len = 4; }
     else if (t < t42) { first = 4 * t4 + 2 * (t - t4); len = 2; }
-    else { first = 4 * t4 + 2 * job.t2 + (t - t42); len = 1; }
+    else { first = 4 * t4 + 2 * t2 + (t - t42); len = 1; }
 }
 
 // scalars[] slots (LDS, per workgroup).  [0, S_KEEP0) are per-frame: cleared when a frame ends; [S_KEEP0, S_COUNT) live across frames.
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
     unsigned next_draw = 0;
     // draws below this are real tickets (the first gridDim.x tickets are the groups' own; a launch may have more groups than tickets --
     // the surplus only ever takes frames from the retry queue)
-    const unsigned fresh_draws = (unsigned)job.n_tickets > gridDim.x ? (unsigned)job.n_tickets - gridDim.x : 0u;
+    auto fresh_draws = [&]() -> unsigned { const unsigned nt = (unsigned)PSX_JOB_INT(n_tickets); return nt > gridDim.x ? nt - gridDim.x : 0u; };     // (made where it is asked for: hand_on, rarely)
     // a group's first frame is its own index (no waiting for an atomic every group issues at the same moment); the counter
     // hands out the frames after those
     if (tid == 0) {
@@ -891,22 +898,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // phases, and still a time-interleaved sample of the batch (which is what real, slowly varying video wants).
         unsigned f0 = blockIdx.x;
         if ((f0 | 7u) < gridDim.x) f0 = (f0 & ~7u) + (((f0 & 7u) + (f0 >> 3)) & 7u);
-        L.scalars[S_FRAME] = (int)f0;
+        const int n_tickets = PSX_JOB_INT(n_tickets);
+        L.scalars[S_FRAME] = (int)f0 < n_tickets ? (int)f0 : in_loop(kNoTicket);
         // A group draws the ticket for its NEXT run when it enters the LAST frame of the run in hand -- one frame ahead of the
         // need, and not before: "this group holds a further fresh frame" (what allows it to hand a frame on, hand_on) is then
         // "frames left in the run, or the ticket in hand is a real one", and the draw that comes up blank still marks the moment
         // the group enters its last fresh frame, which is what the retry queue's protocol counts on.
         int first = 0, len = 1;
-        if ((int)f0 < job.n_tickets) ticket_run(job, (int)f0, first, len);
+        if ((int)f0 < n_tickets) ticket_run(job, (int)f0, first, len);
         L.scalars[S_FIDX] = first;
         L.scalars[S_RUN_LEFT] = len - 1;
-        if ((int)f0 >= job.n_tickets) {
+        if ((int)f0 >= n_tickets) {
             // more groups than tickets (a launch of at most one run per group whose frames may be handed on): this group only ever
             // takes frames from the queue; it draws its place there right away
             if (job.retry) {
                 const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
                 const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
-                L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_tickets ? -1 : -2 - (int)h;
+                L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)n_tickets ? -1 : -2 - (int)h;
             }
         } else if (len == 1) {
             next_draw = draw_ticket(job);
@@ -923,15 +931,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             if (parked) next_draw = (unsigned)L.scalars[S_NEXT_DRAW];
             const int left = L.scalars[S_RUN_LEFT];
             bool entered_last;                 // the frame this group moves to is the last of its run
-            if (left > 0 && L.scalars[S_FRAME] < job.n_tickets) {
+            const int held = L.scalars[S_FRAME];
+            if (left > 0 && held != kNoTicket) {
                 L.scalars[S_RUN_LEFT] = left - 1;
                 L.scalars[S_FIDX] = L.scalars[S_FIDX] + 1;
                 entered_last = left == 1;
             } else {
-                const int t = L.scalars[S_FRAME] < job.n_tickets ? (int)(next_draw + gridDim.x) : in_loop(0x7FFFFFFF);    // (a group that only takes frames from the queue holds no ticket)
+                const int n_tickets = PSX_JOB_INT(n_tickets);
+                int t = held != kNoTicket ? (int)(next_draw + gridDim.x) : in_loop(kNoTicket);    // (a group that only takes frames from the queue holds no ticket)
+                if (t >= n_tickets) t = in_loop(kNoTicket);
                 L.scalars[S_FRAME] = t;
                 entered_last = false;
-                if (t < job.n_tickets) {
+                if (t != kNoTicket) {
                     int first, len;
                     ticket_run(job, t, first, len);
                     L.scalars[S_FIDX] = first;
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     L.scalars[S_RUN_LEFT] = 0;
                     const unsigned long long w = atomicAdd(queue_state(job), 1ull << kQueueHeadShift);
                     const unsigned h = (unsigned)(w >> kQueueHeadShift) & kQueueMask, reserved = (unsigned)(w >> kQueueReservedShift) & kQueueMask;
-                    L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)job.n_tickets ? -1 : -2 - (int)h;
+                    L.scalars[S_QUEUE] = reserved > h ? (int)h : (unsigned)w >= (unsigned)n_tickets ? -1 : -2 - (int)h;
                 }
             }
             if (entered_last) next_draw = draw_ticket(job);
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         asm volatile("" : "+v"(tid_f));
         const int tid = tid_f;               // shadows the kernel-scope copy on purpose
         int f = L.scalars[S_FIDX];
-        if (L.scalars[S_FRAME] >= job.n_tickets && !L.scalars[S_REPILOT]) {      // (S_REPILOT: the frame in hand -- one taken from the queue -- starts over)
+        if (L.scalars[S_FRAME] == kNoTicket) {
             // No fresh frame left for this group: frames that other groups handed on instead of running another pass over them
             // (see the end of the pass loop).  Everything here goes through read-modify-write atomics -- the queue is shared by
             // groups on all XCDs, whose L2s are not coherent for plain loads.  A group leaves when it finds the queue empty;
@@ -980,6 +991,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // waits only once every group of the launch has started, and not for ever; a group that leaves marks its slot
                 // abandoned on the way out, and whoever reserves that slot later learns it from the exchange and keeps its frame.
                 // (Two contexts' launches sharing the GPU ran 4x slower while waiting groups sat out their patience.)
+                int got = -1;
+                // (a frame taken from the queue that starts over from the pilot -- S_REPILOT, at the end of the frame loop -- comes through
+                //  here again: it is still in hand.  The test stands HERE, with thread 0 on the cold side: as a second condition of the
+                //  branch above it cost the 16-wavefront shape 1.7 % on every frame)
+                if (L.scalars[S_REPILOT]) {
+                    got = L.scalars[S_RETRY];
+                } else {
                 const int q = L.scalars[S_QUEUE];
                 const unsigned h = q >= 0 ? (unsigned)q : (unsigned)(-2 - q);
                 bool there = q >= 0;
@@ -987,10 +1005,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     const unsigned long long w = queue_peek(queue_state(job), looks);
                     const unsigned started = queue_peek(&job.ticket[kStartedWord], looks);
                     if (((unsigned)(w >> kQueueReservedShift) & kQueueMask) > h) { there = true; break; }
-                    if ((unsigned)w >= (unsigned)job.n_tickets) break;
+                    if ((unsigned)w >= (unsigned)PSX_JOB_INT(n_tickets)) break;
                     // a group that has not started may be waiting for THIS group's place on a CU: then nobody waits
-                    if (started < gridDim.x || looks >= job.retry_patience) {
-                        if (h < (unsigned)job.retry_cap) {
+                    if (started < gridDim.x || looks >= PSX_JOB_INT(retry_patience)) {
+                        if (h < (unsigned)PSX_JOB_INT(retry_cap)) {
                             if (atomicCAS(&retry_slots(job)[h], (unsigned)in_loop((int)kRetryEmpty), (unsigned)in_loop((int)kRetryAbandoned)) != kRetryEmpty) there = true;      // filled this very moment
                             else atomicAdd(leave_word(job), 0x10000ull);          // a note for the group that re-arms the queue
                         }
@@ -998,7 +1016,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     }
                     __builtin_amdgcn_s_sleep(64);
                 }
-                int got = -1;
                 if (there) {
                     // The slot is filled right after it was reserved: the pusher sits between two adjacent atomics, and it is resident
                     // (it pushes from inside its frame loop).  Should it never come -- a faulted or preempted pusher -- the wait ends
@@ -1019,6 +1036,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         got = (int)(v >> 24);
                         retry_slots(job)[h] = (unsigned)in_loop((int)kRetryEmpty);          // vacated for the next launch (nobody looks at it again in this one)
                     }
+                }
                 }
                 L.scalars[S_RETRY] = got;
             }
@@ -1042,9 +1060,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const int32_t* b_sizes;
         int fl;                                            // index inside its batch
         int bi = 0;
-        fl = f;
+        fl = fu;                                           // (the scalar copy: the frame's address below is then scalar arithmetic -- made from the vector copy it stayed in two vector registers, read back with two v_readfirstlane in every macroblock)
         b_sizes = job.batch[0].max_sizes;                  // one batch (the common launch): plain kernel arguments, nothing to look up
-        frame = job.batch[0].frames + (size_t)f * job.frame_stride;
+        frame = job.batch[0].frames + (size_t)fu * job.frame_stride;
         if (PSX_BATCHES_MANY()) {                           // (straight-line scalar code: a loop here cost the 12-wavefront shape two vector registers it does not have)
             BatchPtr bt = batch_table();
             FirstPtr ft = (FirstPtr)(bt + kMaxBatches);
@@ -1360,7 +1378,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
         const int dts = L.scalars[S_DISTRUST];
         const int rp = L.scalars[S_REPILOT];     // this frame is being started over from the pilot (below): the verdict that sent it back
-        const bool distrust = job.trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : job.trust_mode == 2;
+        const int trust_mode = PSX_JOB_INT(trust_mode);
+        const bool distrust = trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : trust_mode == 2;
         const bool trust_hint = hint_ok && (local || !distrust) && rp == 0;
         if (tid == 0) {
             L.scalars[S_ABORTS_LEFT] = rp ? 1 : 2;          // (a frame sent back to the pilot has used one)
@@ -1596,8 +1615,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                     unsigned ck_s1 = 0, ck_sq = 0;
                     // (a pass that has run out of staging room -- S_STG_NEXT past the area: offsets above 16 bits have spilled into the
                     //  records' bit counts -- keeps the default margin: its stream is not going to be used anyway)
-                    const bool records_ok = L.scalars[S_STG_NEXT] <= job.stg_words;
-                    if (judge && emit_scale && records_ok) {
+                    // (an atomic load, inside the judge's branch: as a plain load the compiler hoisted it to the top of the macroblock
+                    //  loop -- a read and a wait for ALL outstanding LDS traffic, the ticket draw included, in every macroblock of
+                    //  every wavefront: 1.5 % of the kernel)
+                    bool records_ok = false;
+                    if (judge && emit_scale) records_ok = __hip_atomic_load(&L.scalars[S_STG_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= job.stg_words;
+                    if (records_ok) {
                         for (int t = lane; t < check_t; t += 64) {
                             const OrderPtr oe = (OrderPtr)(order_b + (uint32_t)t * 8u);
                             if ((int)oe[0] < 0) {
@@ -1626,7 +1649,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             float var = (float)ck_sq / n - mean * mean;
                             var = var > 0.0f ? var : 0.0f;
                             const float se = 4.0f * __builtin_sqrtf(var * n * (1.0f - n / (float)nmb)) * ((float)nmb / n);
-                            margin = (int)(se * (float)job.ck_margin * 0.001f);
+                            margin = (int)(se * (float)PSX_JOB_INT(ck_margin) * 0.001f);
                         }
                         int g = mdec_search_checkpoint_bits(*srch, count_scale, (int)pa, emit_scale, (int)pb, limit_bits, fixed_bits, margin);
                         // A verdict FAR from where a PILOTED frame started is not taken: it is a two-point extrapolation from a quarter of
@@ -1804,6 +1827,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         QuantK ek;
                         ek.inv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(k << 2, __builtin_bit_cast(int, ke.inv)));
                         ek.bias = __builtin_fmaf(0.25f, ek.inv, 0.5f);
+                        // (the survivors' slots, below: the base is wave-uniform and lives in a spilled scalar register.  Fetched HERE, in
+                        //  front of the table look-ups: fetched where it is used, behind them, the compiler has put a wait for ALL
+                        //  outstanding LDS traffic next to the reload -- one exposed LDS round trip per block, 1.5 % of the kernel)
+                        uint32_t kbase = (uint32_t)(uintptr_t)(clist + 64);
+                        if (low) asm volatile("" : "+s"(kbase));
                         if (low) {
                             const int ka = __builtin_amdgcn_update_dpp(kcarry_a, k, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 <- carry
                             if (do_count) {
@@ -1828,7 +1856,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                             static_assert(single || !low, "a list at the count scale is one chunk");
                             const uint64_t sm = ballot_ne0(q) | ballot_eq0(k);     // (dead lanes: |n| = 0 at position 63)
                             ncodes = (int)__builtin_popcountll(sm);
-                            const uint32_t kslot = (uint32_t)(uintptr_t)(clist + 64 + wave::popc_below(sm));
+                            const uint32_t kslot = kbase + 4u * (uint32_t)wave::popc_below(sm);
                             unsigned long long sv;
                             asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
                                          : "=&s"(sv) : "s"(sm), "v"(kslot), "v"(k) : "memory");          // survivors only
@@ -2021,7 +2049,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 // 170); retries are now drawn like tickets.  The result of a frame never depends on who encodes it or from which guess.
                 auto hand_on = [&](const MdecPass& np) -> bool {
                     if (!job.retry || np.done || !np.emit_scale || L.scalars[S_RETRY] != 0 ||
-                        (L.scalars[S_RUN_LEFT] == 0 && (unsigned)L.scalars[S_NEXT_DRAW] >= fresh_draws)) return false;
+                        (L.scalars[S_RUN_LEFT] == 0 && (unsigned)L.scalars[S_NEXT_DRAW] >= fresh_draws())) return false;
                     const unsigned slot = (unsigned)(atomicAdd(queue_state(job), 1ull << kQueueReservedShift) >> kQueueReservedShift) & kQueueMask;
                     if (atomicExch(&retry_slots(job)[slot], (unsigned)f | ((unsigned)np.emit_scale << 24)) == kRetryAbandoned) {    // (the host sizes the queue for one entry per frame)
                         atomicExch(&retry_slots(job)[slot], (unsigned)in_loop((int)kRetryEmpty));      // the group this slot belonged to has left: the frame stays here
@@ -2131,7 +2159,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             // from the batch's answers otherwise.  Not "the last frame finished": the frames that finish last are the ones
             // that needed a second pass, i.e. the minority answer -- it would poison the start of every following launch
             // (measured: 48 % of the frames restarted at the quarter mark instead of 16 %).
-            if (scale < 64 && f == job.n_frames - 1) *job.hint = (unsigned)scale | ((unsigned)max_size << 8);
+            if (scale < 64 && f == PSX_JOB_INT(n_frames) - 1) *job.hint = (unsigned)scale | ((unsigned)max_size << 8);
             L.scalars[S_HINT] = scale < 64 ? scale : 0;
             L.scalars[S_HINT_BUDGET] = max_size;
             L.scalars[S_HINT_FRAME] = f;
@@ -2353,7 +2381,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                 if (tid == 0) w = atomicAdd(queue_state(job), 0ull);
                 const unsigned wh = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32));
                 unsigned head = (wh >> (kQueueHeadShift - 32)) & kQueueMask;
-                if (head > (unsigned)job.retry_cap) head = (unsigned)job.retry_cap;
+                const unsigned cap = (unsigned)PSX_JOB_INT(retry_cap);
+                if (head > cap) head = cap;
                 for (unsigned i = ((wh >> (kQueueReservedShift - 32)) & kQueueMask) + (unsigned)tid; i < head; i += 64u) retry_slots(job)[i] = kRetryEmpty;
             }
             if (tid == 0) {

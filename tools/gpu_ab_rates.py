@@ -2,7 +2,9 @@
 """A/B of two builds of the library on ONE box (box-to-box spread is about 1.5 %, more than a kernel revision's fixed costs):
 one process per (library, round), alternating; each prints the in-order and two-lane time per 1000-frame launch of the content
 class.  usage: python tools/gpu_ab_rates.py <libA.so> <libB.so> [more.so ...] [kind ...] [--rounds 3] [--json out.json]
-(child: PSXAV_HIP_LIB=<lib> python tools/gpu_ab_rates.py --child kind)"""
+(child: PSXAV_HIP_LIB=<lib> python tools/gpu_ab_rates.py --child kind)
+An older revision's library: git worktree add /tmp/k36 <commit>; make -C /tmp/k36/psxavenc_amd/csrc; cp /tmp/k36/psxavenc_amd/libpsxav_hip.so
+build_ab/libpsxav_hip_k36.so (build_ab/*.so is not tracked; it travels to the GPU box with the snapshot)."""
 import json
 import os
 import subprocess

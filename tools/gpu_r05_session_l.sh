@@ -25,4 +25,6 @@ bash tools/gpu_r05_xacd_pmc.sh gated 5 > $O/r05l_xacd_gated.log 2>&1
 make -s -C examples percall_bench; ./examples/percall_bench 2000 300 300 1 > $O/r05l_percall_sweep.json 2>&1
 ./oracle/cpu_bench spucall oracle/_ref/libpsxav_ref.so > $O/r05l_cpu_spucall.json
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/r05l_bench_default.json 2> $O/r05l_bench_default.err; tail -4 $O/r05l_bench_default.err
+[ -f build_ab/libpsxav_hip_k36.so ] && timeout 1200 python tools/gpu_ab_rates.py build_ab/libpsxav_hip_k36.so psxavenc_amd/libpsxav_hip.so a4 a8 mixed v3a4 --rounds 3 --json $O/r05l_ab_k36_vs_final.json > $O/r05l_ab.log 2>&1
+timeout 900 python tools/gpu_r05_diag.py a4 a8 mixed v3a4 --json $O/r05l_diag.json > $O/r05l_diag.log 2>&1
 find $O -name "*.db" -delete; du -sh $O
