@@ -1150,6 +1150,8 @@ def bench_strcd(args):
             m.close()
             return dt, o
         try:
+            if args.no_secondary:
+                raise RuntimeError("skipped (--no-secondary: every launch of the process belongs to a whole step, for the counter passes)")
             s_v = strmux.settings(fmt=strmux.FORMAT_STRCD, codec=0, width=w, height=h, fps_num=15, fps_den=1, cd_speed=2, channels=0)
             dt_v, _ = timed_dev(s_v, d_frames, None, 20)
             pv = strmux.plan(s_v, n, 0)
@@ -1164,6 +1166,8 @@ def bench_strcd(args):
         frames0 = d_frames[0].cpu().numpy()
         pcm0 = d_pcm[0].cpu().numpy()
         try:
+            if args.no_secondary:
+                raise RuntimeError("skipped (--no-secondary)")
             sectors = np.zeros((p.n_sectors, p.sector_size), np.uint8)
             for _ in range(3):
                 strmux.encode(s, frames0, pcm0, device=local_rank, out=sectors)
@@ -1182,11 +1186,14 @@ def bench_strcd(args):
         import str_reference_loop as R
         k = min(24, n)
         pk = pcm0[:2 * 2016 * 30]
-        sub, _ = mux.encode_device(s, d_frames[0, :k].contiguous(), torch.from_numpy(pk).to(dev))
-        sub = sub.cpu().numpy()[0]
-        osub, _, _ = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames0[:k], pk)
-        parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub, osub)),
-                  "streams_equal_host_path": legs.get("host_buffers_one_stream", {}).get("equals_device_path")}
+        if args.no_secondary:
+            parity = None
+        else:
+            sub, _ = mux.encode_device(s, d_frames[0, :k].contiguous(), torch.from_numpy(pk).to(dev))
+            sub = sub.cpu().numpy()[0]
+            osub, _, _ = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames0[:k], pk)
+            parity = {"sectors_checked": int(osub.shape[0]), "bit_exact": bool(sub.shape == osub.shape and np.array_equal(sub, osub)),
+                      "streams_equal_host_path": legs.get("host_buffers_one_stream", {}).get("equals_device_path")}
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             ref = os.path.join(ROOT, "oracle", "_ref", "libpsxav_ref.so")
@@ -1203,6 +1210,13 @@ def bench_strcd(args):
         total = p.n_sectors * S * world * args.steps
         alg = ((w * h * 3 // 2) * p2.n_frames_encoded + na * 4 + p.n_sectors * p.sector_size) * S
         version = _lib.lib().psxhip_version().decode()
+        try:
+            _lib.lib().psxhip_adpcm_kernel_rev.restype = __import__("ctypes").c_char_p
+            arev = _lib.lib().psxhip_adpcm_kernel_rev().decode()
+        except Exception:
+            arev = "?"
+        str_key = "strcd S=%d frames=%d kind=%d | %s, %s" % (S, n, args.audio_kind, version, arev)
+        traffic, traffic_src, pmc = _profile_traffic(str_key)
         print(json.dumps({
             "metric": "strcd_v2_320x240_sectors_per_sec", "value": round(total / elapsed, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
@@ -1220,8 +1234,10 @@ def bench_strcd(args):
             "roofline": {"bound": "hbm", "kernel": "whole step: mdec_encode_frames_kernel + str_video_sector_kernel beside adpcm_chunks_kernel (speculate, verify) + xa_assemble_kernel",
                          "achieved": round(alg * args.steps / elapsed / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": None, "traffic_note": "a step is several kernels on two streams; the frame kernel on this budget cycle alone: profiles/pmc_index.json key "
-                                                          "'sbs codec=0 320x240 budget=cycle(16128,18144,18144,18144) ...' (python bench.py --budget-cycle 16128,18144,18144,18144)",
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_key": str_key, "algorithmic_bytes_per_launch": alg,
+                         "traffic_note": "per STEP: the counters of every kernel of a step added up (tools/gpu_r05_strcd_pmc.sh, tools/make_strcd_profile_summary.py); the frame kernel "
+                                         "on this budget cycle alone: profiles/pmc_index.json key 'sbs codec=0 320x240 budget=cycle(16128,18144,18144,18144) ...'",
+                         "per_kernel_counters": (pmc or {}).get("kernels"),
                          "video_leg_achieved": legs.get("video_only_all_sectors_video", {}).get("algorithmic_gbs"),
                          "note": "device-resident; the step's time is the XA tracks' verify passes (the tonal test signal), not bytes"},
             "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
