@@ -536,13 +536,50 @@ def test_single_frame_calls_follow_the_content(torch_cuda, monkeypatch):
         t = (C.c_ulonglong * NT)()
         _lib.check(_lib.lib().psxhip_mdec_read_stats(enc._h, t, NT, 0))
         rec = int(t[8 + 4 * 1024 + 16])
-        seen.append((rec & 0xFF, (rec >> 16) & 0xFF, rec >> 24))       # first guess, answer, passes
+        seen.append((rec & 0xFF, (rec >> 16) & 0xFF, (rec >> 24) & 0xFF))       # first guess, answer, passes
     enc.close()
     calm_scale, busy_scale = seen[1][1], seen[3][1]
     assert busy_scale > calm_scale + 2, seen
     for k in (1, 3, 4, 6):                   # the second call on the same content starts from the right scale ...
         assert seen[k][0] == seen[k][1], seen
     assert seen[2][0] == calm_scale and seen[5][0] == busy_scale, seen      # ... the first one after a cut from the old one
+
+
+def test_scene_cuts_send_frames_back_to_the_pilot(torch_cuda, monkeypatch):
+    """Scene-structured content through consecutive launches of one context (psxavenc_amd/mixed.py: cuts between noise amplitudes,
+    hand-made flat / hard-edged frames): a frame that starts from a hint and is stopped at the quarter mark with a verdict FAR from
+    it takes one more turn of the frame loop, from the pilot (mdec-k3.7) -- frames taken from the retry queue included.  The
+    diagnostics instantiation's per-frame records show that such frames exist; every output byte against the oracle, launch
+    after launch (the verdict on foreign hints travels from one launch to the next)."""
+    import ctypes as C
+    from psxavenc_amd import _lib, mixed
+    torch = torch_cuda
+    monkeypatch.setenv("PSXHIP_MDEC_STATS", "1")
+    w, h, budget, n, launches = 320, 240, 8192, 768, 3
+    frames = mixed.frames_host(O, w, h, 11, 100, n * launches)
+    want, want_res, rc = O.mdec_encode(0, w, h, frames, budget)
+    assert rc == 0
+    enc = encoder(0, w, h, budget)
+    NT = 8 + 4 * 1024 + 16 + 2048
+    sent_back = far_first_guess = 0
+    for k in range(launches):
+        d = torch.from_numpy(frames[k * n:(k + 1) * n]).to("cuda:0")
+        d_out, d_res = enc.encode_frames_device(d, budget)
+        torch.cuda.synchronize()
+        assert_same(d_out.cpu().numpy()[:, :budget], d_res.cpu().numpy(), want[k * n:(k + 1) * n], want_res[k * n:(k + 1) * n], "launch %d" % k)
+        t = (C.c_ulonglong * NT)()
+        _lib.check(_lib.lib().psxhip_mdec_read_stats(enc._h, t, NT, 1))
+        rec = np.array(list(t)[8 + 4 * 1024 + 16:8 + 4 * 1024 + 16 + n], dtype=np.uint64)
+        guess, abort, passes = (rec & 0xFF).astype(int), ((rec >> 8) & 0xFF).astype(int), ((rec >> 24) & 0xFF).astype(int)
+        first = ((rec >> 32) & 0x3F).astype(int)             # the scale of the first pass of the frame's LAST attempt
+        far = np.where(guess > 8, guess >> 2, 2)
+        cut = (abort != 0) & (np.abs(abort - guess) >= far)
+        far_first_guess += int(cut.sum())
+        # a frame that was sent back: its last attempt does not start where its first guess was (the pilot chose), and it took >= 2 passes
+        sent_back += int((cut & (passes >= 2) & (np.abs(first - guess) > 1)).sum())
+    enc.close()
+    assert far_first_guess >= 5, far_first_guess          # the sequence has a cut every ~17 frames
+    assert sent_back >= 1, (sent_back, far_first_guess)
 
 
 # ---------------------------------------------------------------- several devices behind one call (psxhip_multi.cpp)
