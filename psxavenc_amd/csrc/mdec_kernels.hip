@@ -1361,29 +1361,44 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         // on content whose answer flips between two scales (640x480 at 8 KiB, noise +-4: one frame in eight lands on 5 instead of
         // 6) a pilot after every miss did worse than the hint it replaced -- a dozen macroblocks of 1200 are right 60 % of the time
         // there, the hint 87 % -- 1.8 M frames/s became 1.2 M.
-        int hint = L.scalars[S_HINT];
-        int hint_budget = L.scalars[S_HINT_BUDGET];
-        bool local = hint >= 1 && L.scalars[S_HINT_FRAME] == f - 1;
-        if (hint < 1) {
-            const int sh = L.scalars[S_SHARED_HINT];
-            hint = sh & 0xFF;
-            hint_budget = sh >> 8;
-        }
-        const int retry_scale = L.scalars[S_RETRY];
-        if (retry_scale > 0) {             // handed on by another group together with the scale its search wanted next
-            hint = retry_scale;
-            hint_budget = max_size;
-            local = true;
-        }
-        const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
-        const int dts = L.scalars[S_DISTRUST];
-        const int rp = L.scalars[S_REPILOT];     // this frame is being started over from the pilot (below): the verdict that sent it back
-        const int trust_mode = PSX_JOB_INT(trust_mode);
-        const bool distrust = trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : trust_mode == 2;
-        const bool trust_hint = hint_ok && (local || !distrust) && rp == 0;
+        // The decision is thread 0's alone (seven scalars read, a dozen scalar instructions: made by every wavefront it was 1 % of the
+        // uniform headline's instructions): S_PILOT_GUESS = the hint the frame starts from, or 0 -- the pilot runs, and S_PILOT_HI says
+        // where it looks first.
         if (tid == 0) {
+            int hint = L.scalars[S_HINT];
+            int hint_budget = L.scalars[S_HINT_BUDGET];
+            bool local = hint >= 1 && L.scalars[S_HINT_FRAME] == f - 1;
+            if (hint < 1) {
+                const int sh = L.scalars[S_SHARED_HINT];
+                hint = sh & 0xFF;
+                hint_budget = sh >> 8;
+            }
+            const int retry_scale = L.scalars[S_RETRY];
+            if (retry_scale > 0) {             // handed on by another group together with the scale its search wanted next
+                hint = retry_scale;
+                hint_budget = max_size;
+                local = true;
+            }
+            const bool hint_ok = hint >= 1 && hint <= 63 && hint_budget == max_size;
+            const int dts = L.scalars[S_DISTRUST];
+            const int rp = L.scalars[S_REPILOT];     // this frame is being started over from the pilot (the end of the frame loop): the verdict that sent it back
+            const int trust_mode = PSX_JOB_INT(trust_mode);
+            const bool distrust = trust_mode == 0 ? ((dts & 1) != 0 || (dts >> 8) >= 2) : trust_mode == 2;
+            const bool trust_hint = hint_ok && (local || !distrust) && rp == 0;
             L.scalars[S_ABORTS_LEFT] = rp ? 1 : 2;          // (a frame sent back to the pilot has used one)
             L.scalars[S_FOREIGN] = hint_ok && !local ? hint : 0;
+            L.scalars[S_PILOT_GUESS] = trust_hint ? hint : 0;
+            int h0 = hint_budget == max_size ? hint : 0;        // (not trusted, or for another budget: it still says where to look first)
+            if (rp) {
+                h0 = rp;
+                L.scalars[S_REPILOT] = in_loop(0);
+            }
+            if (h0 < 1) {
+                // no frame of its own yet: another group's last answer for the same budget is a good place to start looking
+                const int sh = L.scalars[S_SHARED_HINT];
+                if ((sh >> 8) == max_size) h0 = sh & 0xFF;
+            }
+            L.scalars[S_PILOT_HI] = h0;
         }
         // A frame started from a hint (no pilot) whose first pass is stopped with a verdict FAR from the hint -- a scene cut: the
         // neighbour's answer said 23 and the checkpoint's projection says 3 -- starts over from the pilot: the verdict is a
@@ -1404,10 +1419,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         int n_pass = 0, first_abort = 0, guess0 = 0;      // (first_abort, guess0: diagnostics)
         int guess;
         MdecSearch* srch = (MdecSearch*)&L.scalars[S_SEARCH];
-        if (trust_hint) {
-            if (tid == 0) L.scalars[S_PILOT_GUESS] = hint;
-            group_sync(1);
-        } else {
+        group_sync(1);
+        if (L.scalars[S_PILOT_GUESS] == 0) {
         float cfp[kPilotPerWave][6];
 #pragma unroll
         for (int i = 0; i < kPilotPerWave; i++) {
@@ -1436,13 +1449,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         if (tid == 0) {
             L.scalars[S_PILOTED] = 1;
-            int h0 = hint_budget == max_size ? hint : 0;        // (not trusted, or for another budget: it still says where to look first)
-            if (rp) h0 = rp;
-            if (h0 < 1) {
-                // no frame of its own yet: another group's last answer for the same budget is a good place to start looking
-                const int sh = L.scalars[S_SHARED_HINT];
-                if ((sh >> 8) == max_size) h0 = sh & 0xFF;
-            }
+            const int h0 = L.scalars[S_PILOT_HI];
             // The pilot is steered by the search's own two-point model (mdec_pilot_next, mdec_search.h; its state is a MdecSearch of
             // ESTIMATES kept where the exact search's state will live -- that one is set up after the pilot): a hint is checked first
             // (h0 - 1, h0), then the model's prediction and its neighbours -- two rounds and five evaluations on average, where
@@ -1456,7 +1463,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
             L.scalars[S_PILOT_SCALE0 + 1] = pl.s[1];
             L.scalars[S_PILOT_SCALE0 + 2] = pl.s[2];
             L.scalars[S_PILOT_LO] = in_loop(0);       // rounds evaluated so far
-            L.scalars[S_PILOT_HI] = h0;               // the hint (the model's answer while it has nothing to go on)
         }
         for (;;) {
             group_sync(1);
@@ -1496,14 +1502,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
         }
         }
         guess = L.scalars[S_PILOT_GUESS];
-        if (STATS) { guess0 = rp ? carry_guess0 : guess; if (rp) first_abort = carry_abort; }
+        if (STATS) { guess0 = carry_pass ? carry_guess0 : guess; if (carry_pass) first_abort = carry_abort; }
         mark(2);   // pilot
 
         // ---- exact search (mdec_search.h): the state lives in LDS, thread 0 advances it between passes; every pass is
         //      described by two scalars
         if (tid == 0) {
             L.scalars[S_NEXT_DRAW] = (int)next_draw;
-            if (rp) L.scalars[S_REPILOT] = in_loop(0);          // (everybody read it before the barrier above)
             MdecSearch st;
             search_reset(st);
             MdecPass np;

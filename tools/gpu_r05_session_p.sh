@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r05p; mkdir -p $O
-i=2
+i=3
 for lib in psxavenc_amd/libpsxav_hip.so; do
   i=$((i+1))
   for shape in "a4_300mb --frames 1000" "a4_1200mb --width 640 --height 480 --budget 32768 --frames 250" "a4_70mb --width 160 --height 112 --budget 2048 --frames 4000"; do
