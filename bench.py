@@ -306,6 +306,7 @@ def _main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="sbs: contexts / streams the launches are dealt over (default 1: in-order launches on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-only", action="store_true", help="strcd: nothing but whole steps in the process -- no legs, no parity run (for the counter passes of tools/gpu_r05_strcd_pmc.sh)")
     ap.add_argument("--no-secondary", action="store_true", help="sbs: skip the untimed secondary measurements (noise +-8, cold context)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--check-frames", type=int, default=64, help="frames diffed against the oracle after timing")
@@ -1150,8 +1151,8 @@ def bench_strcd(args):
             m.close()
             return dt, o
         try:
-            if args.no_secondary:
-                raise RuntimeError("skipped (--no-secondary: every launch of the process belongs to a whole step, for the counter passes)")
+            if args.steps_only:
+                raise RuntimeError("skipped (--steps-only: every launch of the process belongs to a whole step, for the counter passes)")
             s_v = strmux.settings(fmt=strmux.FORMAT_STRCD, codec=0, width=w, height=h, fps_num=15, fps_den=1, cd_speed=2, channels=0)
             dt_v, _ = timed_dev(s_v, d_frames, None, 20)
             pv = strmux.plan(s_v, n, 0)
@@ -1166,8 +1167,8 @@ def bench_strcd(args):
         frames0 = d_frames[0].cpu().numpy()
         pcm0 = d_pcm[0].cpu().numpy()
         try:
-            if args.no_secondary:
-                raise RuntimeError("skipped (--no-secondary)")
+            if args.steps_only:
+                raise RuntimeError("skipped (--steps-only)")
             sectors = np.zeros((p.n_sectors, p.sector_size), np.uint8)
             for _ in range(3):
                 strmux.encode(s, frames0, pcm0, device=local_rank, out=sectors)
@@ -1186,7 +1187,7 @@ def bench_strcd(args):
         import str_reference_loop as R
         k = min(24, n)
         pk = pcm0[:2 * 2016 * 30]
-        if args.no_secondary:
+        if args.steps_only:
             parity = None
         else:
             sub, _ = mux.encode_device(s, d_frames[0, :k].contiguous(), torch.from_numpy(pk).to(dev))

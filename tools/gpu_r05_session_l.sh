@@ -28,3 +28,5 @@ make -s -C examples percall_bench; ./examples/percall_bench 2000 300 300 1 > $O/
 [ -f build_ab/libpsxav_hip_k36.so ] && timeout 1200 python tools/gpu_ab_rates.py build_ab/libpsxav_hip_k36.so psxavenc_amd/libpsxav_hip.so a4 a8 mixed v3a4 --rounds 3 --json $O/r05l_ab_k36_vs_final.json > $O/r05l_ab.log 2>&1
 timeout 900 python tools/gpu_r05_diag.py a4 a8 mixed v3a4 --json $O/r05l_diag.json > $O/r05l_diag.log 2>&1
 find $O -name "*.db" -delete; du -sh $O
+bash tools/gpu_r05_strcd_pmc.sh 8 > $O/r05l_strcd_pmc.log 2>&1
+find $O -name "*.db" -delete; du -sh $O

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=gpurun_out/prof_strcd_pmc_S$S
 rm -rf $out; mkdir -p $out
 full="python bench.py --config strcd --str-streams $S --steps 40 --warmup 5 --no-cpu-baseline"
-cmd="python bench.py --config strcd --str-streams $S --steps 6 --warmup 2 --no-cpu-baseline --no-secondary"
+cmd="python bench.py --config strcd --str-streams $S --steps 6 --warmup 2 --no-cpu-baseline --steps-only"
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- $full > $out/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o r -- $cmd > $out/write.log 2>&1
