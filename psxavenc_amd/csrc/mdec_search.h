@@ -138,8 +138,13 @@ PSX_HD int mdec_search_checkpoint_bits(const MdecSearch& s, int a, int pa, int b
                                        int margin) {
     const int room = limit_bits - fixed_bits;
     if (room <= 0) return 0;
-    const bool too_low = b && pb > limit_bits + margin;       // the stream being built will not fit
-    const bool too_high = a && pa <= limit_bits - margin;     // the scale below it fits as well
+    // (what an exact evaluation has settled no projection overrules: a frame on the edge -- the true bits of scale 5 within a
+    //  standard error of the limit -- had its pass at 5 stopped as "will not fit", learned from the exact count of the next pass
+    //  that 5 fits, and had the pass that then emitted 5 stopped by the same projection again: four passes, '5!/6/5!/5')
+    const bool b_settled = b && b == s.best;                                   // known to fit
+    const bool a_settled = a && (a <= s.lo || ((s.fail >> a) & 1ull));         // known not to fit
+    const bool too_low = b && !b_settled && pb > limit_bits + margin;       // the stream being built will not fit
+    const bool too_high = a && !a_settled && pa <= limit_bits - margin;     // the scale below it fits as well
     if (!too_low && !too_high) return 0;
     MdecSearch t = s;
     if (a) mdec_search_note(t, a, pa, 0, limit_bits);
