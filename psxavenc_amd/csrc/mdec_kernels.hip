@@ -1645,7 +1645,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void mdec_encode_frames_kernel(con
                         // How far on the wrong side is "clearly"?  The projection is a sample mean scaled up; its standard error
                         // follows from the spread of the sample's macroblocks (finite-population form).  Stopping costs a quarter
                         // pass and is right when the verdict is; carrying on costs a whole pass when it is wrong: stop when the
-                        // projection is wrong-sided by more than ck_margin / 1000 standard errors (0.8, swept over nine workloads
+                        // projection is wrong-sided by more than ck_margin / 1000 standard errors (1.0; 0.8 until mdec-k3.7's closing session -- swept over nine workloads
                         // with tools/gpu_ckmargin_sweep.py: content whose answer flips between neighbouring scales gains 14 %
                         // over a fixed 5 % margin, stable content is unaffected).
                         int margin = (limit_bits - fixed_bits) / 50;
@@ -2634,7 +2634,7 @@ extern "C" hipError_t psxhip_mdec_launch(const psxhip_mdec_launch_t* a) {
     job.retry_patience = a->retry_patience;
     job.stats = a->d_stats;
     job.prio_pattern = a->prio_pattern;
-    job.ck_margin = a->ck_margin > 0 ? a->ck_margin : 800;
+    job.ck_margin = a->ck_margin > 0 ? a->ck_margin : 1000;
     job.trust_mode = a->trust_mode;
     { constexpr ColCoeffs ck = col_coeffs(); for (int i = 0; i < 16; i++) job.col_k[i] = ck.k[i]; }
     job.trips = (job.nmb + waves_ - 1) / waves_;
