@@ -2538,6 +2538,31 @@ extern "C" int psxhip_mdec_pass_order(int width, int height, int large, uint32_t
     // (fetch 141 MB per 1000 frames of 320x240 against 115 MB of pixels; 123 MB with three quarters of the rounds in raster order).  Scattering all rounds in runs
     // of 3 or 5 neighbours instead (tools/gpu_pass_run_sweep.sh) saves as much but changes what the checkpoint samples -- three
     // adjacent macroblock rows are no sample of a picture -- and moved noisy content by -12 .. +14 %.
+    // (experiment, PSXHIP_MDEC_SAMPLE_CLUSTER=c: the quarter's sample as clusters of c neighbouring macroblocks spread over the frame
+    //  instead of whole rounds of `waves` neighbours -- 18 clusters of 4 where the default has 6 of 12 at 320x240)
+    int cluster = 0;
+    if (const char* e = getenv("PSXHIP_MDEC_SAMPLE_CLUSTER")) cluster = atoi(e);
+    if (cluster > 0 && cluster < waves && trips >= 8) {
+        const int K = (nmb + cluster - 1) / cluster, Q = (trips >> 2) * waves;
+        int stepk = (K * 382 + 500) / 1000;
+        for (;; stepk++) { int x = stepk, y = K; while (y) { const int t = x % y; x = y; y = t; } if (x == 1) break; }
+        char* usedmb = (char*)calloc((size_t)nmb, 1);
+        if (!usedmb) return -1;
+        int t = 0;
+        for (int j = 0; j < K && t < Q; j++) {
+            const int k = (int)(((long long)j * stepk) % K);
+            for (int m = k * cluster; m < (k + 1) * cluster && m < nmb && t < Q; m++) {
+                if (t < cap) out[t] = (uint32_t)(m % nx) | (uint32_t)(m / nx) << 8;
+                usedmb[m] = 1;
+                t++;
+            }
+        }
+        for (int m = 0; m < nmb; m++)
+            if (!usedmb[m]) { if (t < cap) out[t] = (uint32_t)(m % nx) | (uint32_t)(m / nx) << 8; t++; }
+        for (; t < n; t++) if (t < cap) out[t] = kNoMb;
+        free(usedmb);
+        return n;
+    }
     int* seq = (int*)malloc((size_t)trips * sizeof(int));      // ticket round -> raster round (a permutation)
     char* used = (char*)calloc((size_t)trips, 1);
     if (!seq || !used) { free(seq); free(used); return -1; }

@@ -1,17 +1,16 @@
 #!/bin/bash
-# round 5, session O19: a stopped pass's verdict steers the next pass (not the unchanged state's model): bytes, soak, A/B on one box
+# round 5, session O21: clusters of 1 / 2 / 3 for the quarter's sample, and what they cost in fetched bytes
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out
-timeout 900 python -m pytest tests/test_gpu_mdec.py -q -x > $O/r05o_pytest.log 2>&1; echo "pytest rc=$?" >> $O/r05o_pytest.log; tail -2 $O/r05o_pytest.log
-timeout 600 python tools/gpu_soak_mixed.py 12 784 900 > $O/r05o_soak_mixed.log 2>&1; tail -1 $O/r05o_soak_mixed.log
-timeout 1500 python tools/gpu_ab_rates.py build_ab/libpsxav_hip_prev.so psxavenc_amd/libpsxav_hip.so a8 mixed a4 v3a4 v3a8_32k --rounds 2 2>&1
-timeout 600 python tools/gpu_r05_diag.py mixed --json $O/r05o19_diag.json > $O/r05o19_diag.log 2>&1
-python - <<PY
-import json
-d=json.load(open("$O/r05o19_diag.json"))
-for k in ("warm_launch","cold_launch"):
-    w=d["mixed"][k]
-    print(k, w['passes_per_frame'], w['passes_hist_0_1_2_3_4_5plus'], 'ck', w['stopped_at_checkpoint'], w['pass_traces_of_frames_with_3_or_more_passes'][:10])
-print({kk:vv['frames_per_sec'] for kk,vv in d["mixed"]['rates'].items() if kk!='quant_scale_hist_4000_frames'})
-PY
+for c in 0 3 2 1; do
+PSXHIP_MDEC_SAMPLE_CLUSTER=$c timeout 600 python tools/gpu_ab_rates.py psxavenc_amd/libpsxav_hip.so a8 mixed a4 v3a4 v3a8_32k --rounds 1 2>&1 | sed "s/^/cluster=$c /"
+done
+for c in 0 2 1; do
+  for shape in "a4 --frames 1000" "v3 --config sbs_v3 --total-frames 1250"; do
+    tag=${shape%% *}; args=${shape#* }
+    out=$O/r05o21_${tag}_c$c; rm -rf $out; mkdir -p $out
+    PSXHIP_MDEC_SAMPLE_CLUSTER=$c rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- python bench.py --lanes 1 --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-secondary $args > $out/fetch.log 2>&1
+    python tools/rocpd_summary.py $(find $out -name "*.db" | sort) 2>/dev/null | grep "mdec_encode.*FETCH_SIZE" | sed "s/^/fetch cluster=$c $tag /"; find $out -name "*.db" -delete
+  done
+done
