@@ -117,6 +117,10 @@ def stats_run(bb, warm):
     r["first_guess_off_by_one"] = int((np.abs(guess - ans) == 1).sum())
     r["first_guess_off_by_more"] = int((np.abs(guess - ans) > 1).sum())
     r["stopped_at_checkpoint"] = int((ab != 0).sum())
+    dd = np.clip(guess - ans, -4, 4)
+    r["first_guess_minus_answer_hist_-4..+4"] = np.bincount(dd + 4, minlength=9).tolist()
+    hi = ans >= 8
+    r["first_guess_minus_answer_hist_answers_8_and_up"] = np.bincount(dd[hi] + 4, minlength=9).tolist()
     c = collections.Counter(zip(guess.tolist(), ab.tolist(), ans.tolist(), np_.tolist()))
     r["top_cases_guess_abort_answer_passes_count"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[1])[:10]]
     r["cases_with_3_or_more_passes"] = [list(k) + [v] for k, v in sorted(c.items(), key=lambda x: -x[0][3] * 1000 - x[1]) if k[3] >= 3][:16]
