@@ -4,7 +4,7 @@ the 8 ranks in lockstep (parallel.simulate_time_sharded runs parallel.time_shard
 runs): per round, which ranks (re-)ran, for how long, and how many verify passes.  A rank's time on its own GPU is its session's
 time here (sessions run one after the other, each with the whole GPU -- as on 8 GPUs); the predicted wall time of a step is
 sum over rounds of (the slowest rank of the round) + rounds x the exchange (an all-gather of 8 bytes per chain: latency only).
-usage: python tools/gpu_r05_predict_8gpu.py [--seconds 3600] [--world 8] [--json out.json]"""
+usage: python tools/gpu_r05_predict_8gpu.py [--seconds 3600] [--world 8] [--chunk units,warmup] [--kinds 0,2,5] [--json out.json]"""
 import json
 import os
 import sys
@@ -34,7 +34,7 @@ class Timed:
         return out
 
 
-def one(kind, seconds, world, n_ch=8, seed=1):
+def one(kind, seconds, world, n_ch=8, seed=1, chunk=None):
     settings = adpcm.XaSettings(adpcm.PSX_AUDIO_XA_FORMAT_XACD, True, 37800, 4, 1, 0)
     sps = adpcm.xa_get_samples_per_sector(settings)
     n_sectors = int(seconds * 37800 / sps)
@@ -55,6 +55,8 @@ def one(kind, seconds, world, n_ch=8, seed=1):
             lead = np.full(2 * n_ch, lead_sec * 72, np.int32)
             d_units = torch.zeros((n_ch * sec_cnt * 144, 32), dtype=torch.uint8, device="cuda")
             cu, wu = adpcm.pick_chunking(int(chains["n_units"].sum()))
+            if chunk and w > 1:
+                cu, wu = chunk      # (--chunk units,warmup: another chunking for the ranks' shares)
             s = adpcm.AdpcmSession(pcm.reshape(-1), chains, base, 4, 4, d_units=d_units, lead_units=lead, chunk_units=cu, warmup_units=wu)
             keep.append((pcm, d_units, s))
             sessions.append(s)
@@ -93,8 +95,12 @@ def main():
     world = int(argv[argv.index("--world") + 1]) if "--world" in argv else 8
     exchange_ms = 0.1       # an 8-rank all-gather of 136 bytes over xGMI: latency only; 0.1 ms is a generous allowance (RCCL small-message latency is tens of us)
     out = {"seconds_of_audio_per_channel": seconds, "world": world, "exchange_ms_per_round_assumed": exchange_ms, "materials": {}}
-    for kind, name in KINDS.items():
-        sectors, res = one(kind, seconds, world)
+    chunk = tuple(int(x) for x in argv[argv.index("--chunk") + 1].split(",")) if "--chunk" in argv else None
+    out["chunk_override_units_warmup"] = chunk
+    kinds = [int(x) for x in argv[argv.index("--kinds") + 1].split(",")] if "--kinds" in argv else list(KINDS)
+    for kind in kinds:
+        name = KINDS[kind]
+        sectors, res = one(kind, seconds, world, chunk=chunk)
         w1, wn = res["world_1"], res["world_%d" % world]
         asm1 = 8 * 0.205          # sector assembly, 8 channels x 0.205 ms (profiles/r05a_xacd_*_summary.txt), split over the ranks
         t1 = w1["predicted_step_ms_without_exchange"] + asm1
