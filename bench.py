@@ -119,6 +119,90 @@ def _gather_ranks(dist, xdev, values):
     return [o.tolist() for o in outs]
 
 
+LINE_LIMIT = 6144      # bytes: the driver's record keeps the last 8 KB of stdout; the line stays well inside it (tests/test_bench_line.py)
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _scalars(d, n=160, skip=()):
+    """the scalar entries of a dict (strings cut to n characters): what the one-line record keeps of a block"""
+    return {k: _short(v, n) for k, v in (d or {}).items() if k not in skip and (v is None or isinstance(v, (bool, int, float, str)))}
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line stdout carries: the contract's keys for the headline and nothing that grows.  `full` is the complete record
+    (every child's line, counter dumps, notes); it goes to a side file (`detail_file`) and to stderr, never to stdout.  Children are
+    summarised as {value, unit, frac, bit_exact} in config.secondary_summary."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_s", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    c = _scalars(cfg, 420)
+    for k in ("quant_scale_hist", "budget_cycle", "secondary_summary", "legs_summary"):
+        if cfg.get(k) is not None:
+            c[k] = cfg[k]
+    line["config"] = c
+    roof = full.get("roofline") or {}
+    r = _scalars(roof, 140, skip=("note", "traffic_note", "kernel_ms_method", "traffic_key"))
+    if isinstance(roof.get("issue"), dict):
+        r["valu_busy_frac"] = roof["issue"].get("valu_busy_frac")
+    if isinstance(roof.get("step"), dict):
+        r["step_frac"] = roof["step"].get("frac")
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        b = _scalars(cb, 200)
+        if isinstance(cb.get("all_cores"), dict):
+            b["all_cores"] = {k: cb["all_cores"].get(k) for k in ("value", "cores", "nproc")}
+        line["cpu_baseline"] = b
+    else:
+        line["cpu_baseline"] = None
+    line["parity"] = full.get("parity")
+    line["results_sane"] = full.get("results_sane")
+    if full.get("per_rank"):
+        line["per_rank"] = [{k: pr.get(k) for k in ("rank", "frames_per_sec", "sectors_per_sec", "kernel_ms", "roofline_frac", "results_sane") if k in pr} for pr in full["per_rank"]]
+    if full.get("predicted") is not None:
+        line["predicted"] = full["predicted"]
+    line["dist"] = _scalars(full.get("dist")) if full.get("dist") else None
+    line["detail_file"] = detail_path
+    # belt and braces: the line never outgrows the limit, whatever a future key brings along
+    for victim in (("config", "secondary_summary"), ("per_rank",), ("config", "quant_scale_hist"), ("cpu_baseline", "sample"), ("config", "workload")):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        d = line
+        for k in victim[:-1]:
+            d = d.get(k) or {}
+        if victim[-1] in d:
+            d[victim[-1]] = "dropped: line over %d bytes, see detail_file" % LINE_LIMIT
+    return line
+
+
+def _emit(full, args):
+    """full record -> side file + stderr; compact line (<= LINE_LIMIT bytes) -> the last line of stdout"""
+    path = getattr(args, "detail_file", None)
+    if not path:
+        d = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail_%s_n%d.json" % (getattr(args, "config", None) or "run", full.get("n_gpus") or 1))
+        except OSError:
+            path = os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+            fh.write("\n")
+        shown = os.path.relpath(path, ROOT)
+    except OSError:
+        shown = None
+    sys.stderr.write("bench detail: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    line = compact_line(full, shown)
+    s = json.dumps(line)
+    assert len(s) <= LINE_LIMIT, len(s)
+    print(s, flush=True)
+
+
 AUDIO_KINDS = {0: "two tones + noise floor (tonal: a wrong start state survives thousands of units -- the hard case)",
                1: "quiet tone + noise", 2: "white noise, full scale (states coincide within a few units)", 3: "silence",
                4: "one tone, half scale", 5: "gated tone + noise floor (bursts and silence)"}
@@ -251,6 +335,20 @@ PRESETS = {
 }
 
 
+def _predicted(args, world):
+    """What DESIGN section 5 commits to for this preset at this world size, so that a SCALE record reads against the prediction
+    without opening DESIGN.md.  Predictions from one-GPU measurements (profiles/r05_predict_*), never a measured curve."""
+    if args.config == "sbs_v2":
+        return {"value": round(8.7e6 * world), "unit": "frames/s", "basis": "N x 8.7 M: no data-path exchange (DESIGN section 5)"}
+    if args.config == "sbs_v3":
+        v = {1: 1.5e6, 2: 3.6e6, 4: 5.3e6, 8: 14.5e6}.get(world)
+        return {"value": v, "unit": "frames/s", "basis": "10 000 frames strong-sharded; per-rank launches measured on one GPU (DESIGN section 5)"} if v else None
+    if args.config == "xacd" and getattr(args, "audio_kind", 0) == 0:
+        v = {1: 27e6, 2: 35e6, 4: 58e6, 8: 68e6}.get(world)
+        return {"value": v, "unit": "sectors/s", "basis": "lockstep simulation of N sessions on one GPU, profiles/r05_predict_{2,4,8}gpu_xacd.json"} if v else None
+    return None
+
+
 def _report_failure(exc):
     """One JSON line instead of (in front of) a traceback: whichever rank fails says so on stdout -- the driver keeps the tail of
     stdout -- and exits non-zero; the other ranks run into the collective's timeout (--dist-timeout) and report that."""
@@ -288,7 +386,8 @@ def _main():
                          "--steps 20 to time over ten seconds of GPU work: 4800 launches of 1000 320x240 frames)")
     ap.add_argument("--audio-kind", type=int, default=0, help="xacd: synthetic material (psxhip_synth_pcm_device kind): 0 two tones + noise "
                     "floor -- tonal, start-state guesses do not converge, the hard case and the default; 2 white noise; 5 gated tone")
-    ap.add_argument("--str-streams", type=int, default=8, help="strcd: independent streams per psxhip_str_encode_device call (their XA tracks share the verify passes)")
+    ap.add_argument("--str-streams", type=int, default=1, help="strcd: independent streams per psxhip_str_encode_device call (their XA tracks share the verify passes); "
+                    "1 = BASELINE's config 3 (one stream); the eight-streams-per-call rate is measured beside it as a leg")
     ap.add_argument("--batches", type=int, default=4, help="sbs: distinct input batches the launches cycle over")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (config 'sbs v2': 1000)")
     ap.add_argument("--total-frames", type=int, default=None, help="sbs: frames per launch over ALL GPUs (strong scaling; overrides --frames)")
@@ -328,6 +427,7 @@ def _main():
     ap.add_argument("--device-list", default=None,
                     help="sbs: devices for the secondary C-ABI device-list leg (psxhip_mdec_multi_*), e.g. '0,0' to run it on a one-GPU box; "
                          "default: all visible devices when there is more than one")
+    ap.add_argument("--detail-file", default=None, help="where the full record goes (default gpurun_out/bench_detail_<config>_n<N>.json); stdout carries the compact line only")
     ap.add_argument("--no-config-secondaries", action="store_true",
                     help="default run only: skip the other BASELINE configs (sbs_v3 share, xacd, strcd) and the RCCL world-size-1 self-test that "
                          "are run as subprocesses after the timed region")
@@ -594,8 +694,9 @@ def _main():
             "parity": parity,
             "results_sane": all(bool(q[1]) for q in scale_sum),
             "dist": _dist_info(args, dist),
+            "predicted": _predicted(args, world),
         }
-        print(json.dumps(line), flush=True)
+        _emit(line, args)
     for e in encs:
         e.close()
     if dist is not None:
@@ -603,8 +704,8 @@ def _main():
 
 
 def _secondary_summary(sec):
-    """the secondaries' headline numbers in a few dozen bytes, inside `config` (a driver record keeps `config` whole and the tail of
-    the line only): frames/s (sectors/s for the ADPCM / STR children)"""
+    """the secondaries in a few dozen bytes each, inside `config`: in-process figures as bare frames/s, child processes (the other
+    BASELINE configs) as {value, unit, frac, bit_exact}; their full lines are in the detail file"""
     if not sec:
         return None
     out = {}
@@ -622,14 +723,19 @@ def _secondary_summary(sec):
     g(("cold_context", "first_launch_alone", "frames_per_sec"), "cold_context_first_launch")
     g(("mixed_content", "two_lanes", "frames_per_sec"), "mixed_content_two_lanes")
     g(("mixed_content", "one_lane_in_order", "frames_per_sec"), "mixed_content_in_order")
-    g(("mixed_content", "four_batches_one_launch", "frames_per_sec"), "mixed_content_batch_list")
-    g(("mixed_content", "distinct_scales"), "mixed_content_distinct_scales")
     g(("mixed_content", "passes", "passes_per_frame"), "mixed_content_passes_per_frame")
-    g(("sbs_v3_1250", "value"), "sbs_v3_1250_frames_per_sec")
-    g(("xacd_config5", "value"), "xacd_config5_sectors_per_sec")
-    g(("strcd_config3", "value"), "strcd_config3_device_resident_sectors_per_sec")
-    g(("strcd_config3", "config", "legs", "host_buffers_one_stream", "sectors_per_sec"), "strcd_config3_host_buffers_sectors_per_sec")
     g(("per_call_drop_in", "encode_frame_bs_320x240_v2", "us_per_call_median"), "per_call_encode_frame_bs_us")
+    g(("per_call_drop_in", "encode_frame_bs_320x240_v2", "frames_per_sec"), "per_call_encode_frame_bs_frames_per_sec")
+    for name, child in sec.items():
+        if isinstance(child, dict) and ("value" in child or "rc" in child):
+            e = {"value": child.get("value"), "unit": child.get("unit"), "frac": (child.get("roofline") or {}).get("frac"),
+                 "bit_exact": (child.get("parity") or {}).get("bit_exact")}
+            if child.get("error"):
+                e["error"] = _short(str(child["error"]), 60)
+            cfg = child.get("config") or {}
+            if "eight_streams_sectors_per_sec" in cfg:      # config 3: value = ONE stream (BASELINE's config); eight per call beside it
+                e["s8"] = cfg["eight_streams_sectors_per_sec"]
+            out[name] = e
     return out
 
 
@@ -935,11 +1041,14 @@ def _secondary_configs(args):
                                "--launches-per-step", "200", "--no-secondary", "--no-cpu-baseline"] + seed),
     ]
     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "timed_region_s", "scaling", "config", "roofline", "cpu_baseline", "parity",
-            "dist", "error")
+            "dist", "error", "detail_file")
     out = {}
+    ddir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(ddir, exist_ok=True)
     for name, cmd in jobs:
         t0 = time.perf_counter()
         try:
+            cmd = cmd + ["--detail-file", os.path.join(ddir, "bench_detail_child_%s.json" % name)]
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
             line = None
             for ln in reversed(r.stdout.strip().splitlines()):
@@ -1016,10 +1125,8 @@ def bench_xacd(args):
         outs, passes = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank = _gather_ranks(dist, xdev, [elapsed, float(sec_cnt)])
+    elapsed = max(r[0] for r in per_rank)                   # max over ranks
     # ---- the dominant kernel, live: HIP events around the speculate launch (adpcm_chunks_kernel<false, ..>) and around the verify
     #      passes of a few further steps (psxhip_adpcm_session_set_timing: the events are on the session's own stream, inside the call)
     spec_ms, verify_ms = [], []
@@ -1050,6 +1157,7 @@ def bench_xacd(args):
         total_sectors = n_sectors * n_ch * args.steps
         value = total_sectors / elapsed
         alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
+        spec_bytes = (sps * 4 + 144 * (adpcm.RECORD_BYTES + 8)) * sec_cnt * n_ch      # the speculate kernel's own: PCM in, unit records + states out
         from psxavenc_amd import _lib as _plib
         try:
             _plib.lib().psxhip_adpcm_kernel_rev.restype = __import__("ctypes").c_char_p
@@ -1067,7 +1175,7 @@ def bench_xacd(args):
                 slots = 1024 * 2.4e9 / 4.0 * sm * 1e-3
                 kroof["valu_busy_frac"] = round(pmc["valu_insts_per_launch"] / slots, 4)
                 kroof["valu_insts_per_launch"] = pmc["valu_insts_per_launch"]
-        print(json.dumps({
+        _emit({
             "metric": "xa_37800_4bit_stereo_sectors_per_sec", "value": round(value, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dist": _dist_info(args, dist),
@@ -1076,21 +1184,24 @@ def bench_xacd(args):
                        "preset": args.config, "baseline_config": args.baseline_config,
                        "material": AUDIO_KINDS.get(args.audio_kind, str(args.audio_kind)),
                        "verify_passes_last_step": passes, "chunk_units": chunk_units, "warmup_units": warmup_units, "realtime_factor": round(value * sps / 37800.0 / n_ch, 1)},
-            "roofline": {"bound": "hbm", "kernel": "adpcm_chunks_kernel<false, 12> (speculate: every chunk of every chain from a guessed start state)",
-                         "achieved": kroof["achieved"] if kroof else round(alg * args.steps / elapsed / 1e9, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kroof["frac"] if kroof else round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+            "roofline": {"bound": "hbm", "kernel": "whole step: adpcm_chunks_kernel (speculate from guessed start states, verify passes) + 8 x xa_assemble_kernel",
+                         "achieved": round(alg * args.steps / elapsed / 1e9, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_key": xa_key,
                          "algorithmic_bytes_per_launch": alg,
+                         # the dominant kernel alone: ITS bytes (all PCM read once + unit records and per-unit states written) over ITS duration
+                         "speculate_kernel": ({"kernel": "adpcm_chunks_kernel<false, 12>", "kernel_ms": kroof["kernel_ms"], "kernel_ms_all": kroof["kernel_ms_all"],
+                                               "own_bytes": spec_bytes, "achieved": round(spec_bytes / (kroof["kernel_ms"] * 1e-3) / 1e9, 3),
+                                               "frac": round(spec_bytes / (kroof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                               "valu_busy_frac": kroof.get("valu_busy_frac"), "valu_insts_per_launch": kroof.get("valu_insts_per_launch"),
+                                               "method": "HIP events on the session's stream around the speculate launch, 3 steps after the timed region (median)"} if kroof else None),
                          "kernel_ms": kroof["kernel_ms"] if kroof else None,
-                         "kernel_ms_method": "HIP events on the session's stream around the speculate launch, 3 steps after the timed region (median)",
-                         "issue": ({"valu_busy_frac": kroof.get("valu_busy_frac"), "valu_insts_per_launch": kroof.get("valu_insts_per_launch"),
-                                    "note": "SQ_INSTS_VALU of the committed PMC pass / (1024 SIMDs x 2.4 GHz / 4 x this run's kernel time): the kernel is a dependent chain per sound unit, bound by VALU issue"} if kroof else None),
                          "verify_ms": kroof["verify_ms"] if kroof else None,
                          "per_kernel_counters": (pmc or {}).get("kernels"),
-                         "step": {"achieved": round(alg * args.steps / elapsed / 1e9, 3), "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
-                                  "note": "whole step: speculate + verify passes (host-driven) + 8 sector assemblies"},
-                         "note": "algorithmic bytes of the step (PCM in + sectors out) / the speculate kernel's duration: the kernel reads all PCM once and writes 32-byte unit records + 8-byte states (its own traffic: `traffic`)"},
-            "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
+                         "note": "achieved / frac: algorithmic bytes of the step (PCM in + sectors out, SURVEY 8(d)) over the whole step's time -- speculate + verify "
+                                 "passes + sector assemblies; the speculate kernel's own figure is `speculate_kernel` (a dependent chain per sound unit: VALU issue bounds it)"},
+            "cpu_baseline": cpu_baseline, "parity": parity, "predicted": _predicted(args, world),
+            "per_rank": [{"rank": i, "sectors_per_sec": round(n_ch * r[1] * args.steps / r[0], 1), "elapsed_s": round(r[0], 4)} for i, r in enumerate(per_rank)]}, args)
     sess.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -1159,9 +1270,22 @@ def bench_strcd(args):
             legs["video_only_all_sectors_video"] = {"ms_per_step": round(dt_v * 1e3, 4), "sectors_per_sec": round(pv.n_sectors * S / dt_v, 1),
                                                     "frames_per_sec": round(pv.n_frames_encoded * S / dt_v, 1),
                                                     "algorithmic_gbs": round(((w * h * 3 // 2) * pv.n_frames_encoded + pv.n_sectors * pv.sector_size) * S / dt_v / 1e9, 2)}
-            dt_1, _ = timed_dev(s, d_frames[:1].contiguous(), d_pcm[:1].contiguous(), 20)
-            legs["one_stream_per_call"] = {"ms_per_step": round(dt_1 * 1e3, 4), "sectors_per_sec": round(p.n_sectors / dt_1, 1),
-                                           "note": "one stream's XA track alone: 2 chains, bound by how far a wrong start state travels (serial re-encode in the verify passes)"}
+            if S > 1:
+                dt_1, _ = timed_dev(s, d_frames[:1].contiguous(), d_pcm[:1].contiguous(), 20)
+                legs["one_stream_per_call"] = {"ms_per_step": round(dt_1 * 1e3, 4), "sectors_per_sec": round(p.n_sectors / dt_1, 1),
+                                               "note": "one stream's XA track alone: 2 chains, bound by how far a wrong start state travels"}
+            else:       # value is ONE stream (BASELINE's config 3); what a caller with eight independent streams gets from one call
+                S8 = 8
+                f8 = torch.stack([d_frames[0]] + [synth.frames_device(w, h, args.seed + 17 * i, first, n, args.amp, device=local_rank) for i in range(1, S8)])
+                p8 = torch.zeros((S8, na * 2), dtype=torch.int16, device=dev)
+                p8[0] = d_pcm[0]
+                for i in range(1, S8):
+                    for c in range(2):
+                        synth.pcm_device(args.seed, 2 * i + c, 0, na, args.audio_kind, device=local_rank, out=p8[i][c:], pitch=2)
+                dt_8, _ = timed_dev(s, f8, p8, 20)
+                legs["eight_streams_per_call"] = {"ms_per_step": round(dt_8 * 1e3, 4), "sectors_per_sec": round(p.n_sectors * S8 / dt_8, 1),
+                                                  "note": "eight independent streams in one psxhip_str_encode_device call: their XA tracks share the verify passes"}
+                del f8, p8
         except Exception as e:
             legs["error"] = repr(e)
         frames0 = d_frames[0].cpu().numpy()
@@ -1218,7 +1342,7 @@ def bench_strcd(args):
             arev = "?"
         str_key = "strcd S=%d frames=%d kind=%d | %s, %s" % (S, n, args.audio_kind, version, arev)
         traffic, traffic_src, pmc = _profile_traffic(str_key)
-        print(json.dumps({
+        _emit({
             "metric": "strcd_v2_320x240_sectors_per_sec", "value": round(total / elapsed, 2), "unit": "sectors/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "timed_region_s": round(elapsed, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dist": _dist_info(args, dist),
@@ -1227,6 +1351,8 @@ def bench_strcd(args):
                                    % (S, n, p.n_sectors, p.n_video_sectors, p.n_audio_sectors),
                        "preset": args.config, "baseline_config": args.baseline_config, "tail": "reference (filefmt.c:443-450,492-493)",
                        "streams_per_call": S, "frames_encoded_per_stream": p2.n_frames_encoded,
+                       **({"eight_streams_sectors_per_sec": legs["eight_streams_per_call"]["sectors_per_sec"]} if "eight_streams_per_call" in legs else {}),
+                       **({"one_stream_sectors_per_sec": legs["one_stream_per_call"]["sectors_per_sec"]} if "one_stream_per_call" in legs else {}),
                        "frames_per_sec": round(p2.n_frames_encoded * S * world * args.steps / elapsed, 1),
                        "realtime_factor": round(p2.n_frames_encoded * S * world * args.steps / elapsed / 15.0, 1),
                        "material": AUDIO_KINDS.get(args.audio_kind, str(args.audio_kind)),
@@ -1241,7 +1367,8 @@ def bench_strcd(args):
                          "per_kernel_counters": (pmc or {}).get("kernels"),
                          "video_leg_achieved": legs.get("video_only_all_sectors_video", {}).get("algorithmic_gbs"),
                          "note": "device-resident; the step's time is the XA tracks' verify passes (the tonal test signal), not bytes"},
-            "cpu_baseline": cpu_baseline, "parity": parity}), flush=True)
+            "cpu_baseline": cpu_baseline, "parity": parity,
+            "per_rank": [{"rank": i, "sectors_per_sec": round(r[1] / r[0], 1), "elapsed_s": round(r[0], 4)} for i, r in enumerate(per_rank)]}, args)
     mux.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -105,7 +105,9 @@ def test_c_abi_device_list_leg_of_the_bench_line():
                         "--no-config-secondaries", "--device-list", "0,0"], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
     line = _last_json(r.stdout)
     assert r.returncode == 0 and line, (r.stdout[-2000:], r.stderr[-2000:])
-    leg = line["secondary"]["c_abi_device_list"]
+    assert "secondary" not in line          # stdout carries the compact line; the legs are in the detail file it names
+    with open(os.path.join(ROOT, line["detail_file"])) as fh:
+        leg = json.load(fh)["secondary"]["c_abi_device_list"]
     assert "error" not in leg, leg
     assert leg["devices"] == [0, 0] and leg["static"]["bit_exact_vs_device_0"] and leg["tickets"]["bit_exact_vs_device_0"]
     assert sum(d["units"] for d in leg["tickets"]["per_device"]) == leg["frames"]
@@ -130,3 +132,53 @@ def test_a_failing_rank_prints_one_json_error_line():
     assert line is not None and "error" in line, (r.stdout[-1000:], r.stderr[-1000:])
     assert line["rank"] == 1 and line["world_size"] == 3
     assert len(r.stdout.strip().splitlines()) == 1
+
+
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline", "parity")
+
+
+@pytest.mark.gpu
+def test_the_driver_command_prints_one_parsable_line_under_8_kb():
+    """`python bench.py --gpus 1 --steps K --warmup W` exactly as the driver runs it (all children included): the LAST line of stdout is
+    the record, it parses, it is under 8 KB (the driver keeps an 8 KB tail; round 5's 36 KB line was lost), and it carries `roofline`
+    and `cpu_baseline` for the headline and every BASELINE config as a {value, unit, frac, bit_exact} child."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3"], env=_env(), capture_output=True,
+                       text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 8192 and len(r.stdout) < 8192, (len(last), len(r.stdout))
+    line = json.loads(last)
+    for k in REQUIRED_KEYS:
+        assert k in line, k
+    assert line["metric"] == "bs_v2_320x240_frames_per_sec" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    roof, cpu = line["roofline"], line["cpu_baseline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert cpu["value"] > 0 and cpu["cores"] == 1 and cpu["kind"] in ("port", "reference")
+    assert line["parity"]["bit_exact"] is True
+    summ = line["config"]["secondary_summary"]
+    for child in ("sbs_v3_1250", "xacd_config5", "strcd_config3", "rccl_world_size_1"):
+        assert summ[child]["value"] > 0 and summ[child]["bit_exact"] is True, (child, summ[child])
+        assert len(json.dumps(summ[child])) <= 150
+    assert summ["strcd_config3"]["s8"] > summ["strcd_config3"]["value"]          # value = ONE stream (BASELINE's config 3), eight per call beside it
+    with open(os.path.join(ROOT, line["detail_file"])) as fh:
+        full = json.load(fh)
+    assert full["secondary"]["strcd_config3"]["config"]["streams_per_call"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["sbs_v2", "xacd"])
+def test_two_ranks_on_two_distinct_gpus_over_rccl(preset):
+    """RCCL at world size 2 over DISTINCT devices -- only where the lease has two GPUs (skipped on the one-GPU boxes); the line carries
+    per-rank rates, the world size RCCL reports and the prediction DESIGN section 5 commits to."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--config", preset, "--steps", "2", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"] + PRESET_ARGS[preset]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = _last_json(r.stdout)
+    assert r.returncode == 0 and line is not None and "error" not in line, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert line["n_gpus"] == 2 and line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 2
+    assert [x["rank"] for x in line["per_rank"]] == [0, 1] and line["parity"]["bit_exact"] is True
+    assert line["predicted"]["value"] > 0

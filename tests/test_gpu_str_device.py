@@ -112,10 +112,12 @@ def test_audio_shorter_than_video_and_shape_changes_on_one_handle(n_audio_sector
 
 def test_config3_at_1000_frames_device_resident():
     """BASELINE config 3 at its full size, device-resident: 1000 frames 320x240 @15 fps + 37800 Hz 4-bit stereo XA (the tonal test
-    signal: its XA track needs the verify passes) -> 9981 STRCD sectors, every sector against the host-buffer path (itself held to the
-    reference loop by test_strcd_config3_at_1000_frames)"""
+    signal: its XA track needs the verify passes) -> 9981 STRCD sectors, every sector against the reference's sector loop
+    (tests/str_reference_loop.py: filefmt.c:391-520) with the XA sectors from the reference's own psx_audio_xa_encode (libpsxav/adpcm.c
+    compiled unchanged into oracle/_ref) where that build travelled, else from the restatement"""
     import torch
-    from psxavenc_amd import strmux, synth
+    import str_reference_loop as R
+    from psxavenc_amd import strmux
     w, h, n_frames = 320, 240, 1000
     s = strmux.settings()
     frames = O.synth_frames(w, h, n_frames, seed=1, amp=4)
@@ -124,9 +126,10 @@ def test_config3_at_1000_frames_device_resident():
     mux = strmux.StrMuxer((0,))
     d_out, p = mux.encode_device(s, torch.from_numpy(frames).to("cuda:0"), torch.from_numpy(pcm).to("cuda:0"))
     assert p.n_frames_encoded == 998 and p.n_sectors == d_out.shape[1]
-    want, ph = mux.encode(s, frames, pcm)
+    want, qsum, frames_encoded = R.encode_file_str(7, 0, w, h, 15, 1, 2, frames, pcm, xa_encode=O.ref_xa_encode if O.ref() is not None else None)
     got = d_out.cpu().numpy()[0]
+    assert got.shape == want.shape, (got.shape, want.shape)
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "sectors differ: %s" % bad[:8].tolist()
-    assert p.quant_scale_sum == ph.quant_scale_sum
+    assert (p.quant_scale_sum, p.n_frames_encoded) == (qsum, frames_encoded)
     mux.close()
