@@ -75,7 +75,7 @@ def encode_file_str(fmt, codec, w, h, fps_num, fps_den, cd_speed, frames, pcm, c
     else:                                                  # :415-419
         interleave, audio_samples_per_sector, video_sectors_per_block = 1, 0, 1
 
-    audio_state = O.State()                                # :422-423
+    audio_state = None          # :422-423 (zeroed state; the encoder handed in makes its own kind: O.State / the reference's RefState)
     base = (75 * cd_speed) * video_sectors_per_block * fps_den      # :431
     den = interleave * fps_num                                       # :432
     frame_size = float(base) / float(den)                            # :433
