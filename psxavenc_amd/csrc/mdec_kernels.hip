@@ -2475,6 +2475,8 @@ extern "C" hipError_t psxhip_mdec_stage_in_launch(const void* src_mapped, void* 
     return hipGetLastError();
 }
 
+#include "mdec_split.inc"
+
 extern "C" hipError_t psxhip_mdec_fdct_launch(const int16_t* d_in, int16_t* d_out, int n_blocks, void* stream) {
     if (n_blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(mdec_fdct_probe_kernel, dim3((unsigned)((n_blocks + 5) / 6)), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_blocks);

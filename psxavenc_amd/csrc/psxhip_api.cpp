@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -113,6 +114,15 @@ struct psxhip_mdec_ctx {
     uint8_t* d_call_frame;
     size_t call_out_off, call_res_off;
     bool call_disabled;
+    // launches of a few frames: one frame across many workgroups (mdec_split.inc)
+    unsigned char* d_split_ws;        // [kLanes][split_max] per-frame workspaces, all zero between launches
+    size_t split_ws_stride;
+    int split_max;                    // launches of at most this many frames take the split kernel (0: never)
+    unsigned long long* d_split_dbg;  // diagnostics (PSXHIP_MDEC_SPLIT_DBG=1): phase stamps of the last split launch
+    int split_dbg_groups;
+    // diagnostics (PSXHIP_PERCALL_TRACE=1): where a one-frame call's host time goes, printed when the context is destroyed
+    bool call_trace;
+    double call_ns[6];                // copy in, stage-in launch, encode launch, wait, copy out, calls
 };
 
 namespace {
@@ -262,6 +272,23 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     //  would otherwise take two of the device's few hardware queues -- streams are dealt onto them round-robin -- and with three
     //  contexts alive two callers' streams shared one queue: their launches ran one after the other)
     c->n_cu = prop.multiProcessorCount;
+    c->call_trace = getenv("PSXHIP_PERCALL_TRACE") != nullptr;
+    {
+        // one frame across many workgroups, for launches of at most split_max frames (PSXHIP_MDEC_SPLIT_MAX: experiments, 0 = off)
+        c->split_max = 8;
+        if (const char* e = getenv("PSXHIP_MDEC_SPLIT_MAX")) c->split_max = atoi(e);
+        if (c->split_max > 64) c->split_max = 64;
+        psxhip_mdec_split_geo_t g;
+        if (c->split_max > 0 && psxhip_mdec_split_geometry(codec, width, height, max_frame_size, 1, c->n_cu, &g)) {
+            c->split_ws_stride = g.ws_stride;
+            const size_t bytes = (size_t)kLanes * c->split_max * g.ws_stride;
+            HIP_TRY(hipMalloc((void**)&c->d_split_ws, bytes), PSXHIP_ENOMEM);
+            HIP_TRY(hipMemset(c->d_split_ws, 0, bytes), PSXHIP_EDEVICE);
+            if (getenv("PSXHIP_MDEC_SPLIT_DBG")) HIP_TRY(hipMalloc((void**)&c->d_split_dbg, (size_t)c->split_max * c->n_cu * 8 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
+        } else {
+            c->split_max = 0;
+        }
+    }
     // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
     // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
     // of all.  Needs that shape's pass order too, and its (larger) LDS working set to fit.
@@ -308,6 +335,11 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_order_large) (void)hipFree(c->d_order_large);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->call_trace && c->call_ns[5] > 0)
+        fprintf(stderr, "per-call trace (%.0f calls, us per call): copy in %.2f, stage-in launch %.2f, encode launch %.2f, wait %.2f, copy out %.2f\n", c->call_ns[5],
+                c->call_ns[0] / c->call_ns[5] * 1e-3, c->call_ns[1] / c->call_ns[5] * 1e-3, c->call_ns[2] / c->call_ns[5] * 1e-3, c->call_ns[3] / c->call_ns[5] * 1e-3, c->call_ns[4] / c->call_ns[5] * 1e-3);
+    if (c->d_split_ws) (void)hipFree(c->d_split_ws);
+    if (c->d_split_dbg) (void)hipFree(c->d_split_dbg);
     psxhip_mdec_free_staging(c);
     if (c->h_call) (void)hipHostFree(c->h_call);
     if (c->d_call_frame) (void)hipFree(c->d_call_frame);
@@ -324,6 +356,26 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
                             int uniform_max_size, size_t out_stride, hipStream_t stream) {
     int n_frames = 0;
     for (int i = 0; i < nb; i++) n_frames += batches[i].n_frames;
+    // A launch of a few frames: every frame across many workgroups (the reference's own pattern, one frame per call, most of all:
+    // one workgroup would encode it on ONE compute unit while 255 idle)
+    if (nb == 1 && n_frames <= c->split_max && !c->d_stats) {
+        psxhip_mdec_split_t sp;
+        memset(&sp, 0, sizeof sp);
+        if (psxhip_mdec_split_geometry(c->codec, c->width, c->height, c->max_frame_size, n_frames, c->n_cu, &sp.geo)) {
+            sp.d_frames = batches[0].d_frames; sp.d_out = batches[0].d_out; sp.d_results = batches[0].d_results;
+            sp.d_frame_max_sizes = batches[0].d_frame_max_sizes;
+            sp.frame_stride = frame_stride; sp.out_stride = out_stride;
+            sp.width = c->width; sp.height = c->height; sp.codec = c->codec; sp.n_frames = n_frames;
+            sp.uniform_max_size = uniform_max_size; sp.max_frame_size = c->max_frame_size;
+            sp.d_ws = c->d_split_ws + (size_t)lane * c->split_max * c->split_ws_stride;
+            sp.d_lost = c->d_ticket + 128 * lane + 3;
+            sp.d_dbg = c->d_split_dbg;
+            c->split_dbg_groups = sp.geo.segs * n_frames;
+            sp.stream = stream;
+            HIP_TRY(psxhip_mdec_split_launch(&sp), PSXHIP_EDEVICE);
+            return PSXHIP_OK;
+        }
+    }
     // A batch of at most one frame per CU gains nothing from the two-group shape (its point is two frames per CU): such
     // launches use the 16-wavefront shape, which finishes a lone frame sooner -- the drop-in one-frame-per-call pattern most
     // of all.  (Tried and dropped: sending the REMAINDER of a large batch -- the frames past the last full round of
@@ -635,8 +687,13 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
         if (c->h_call) {
             if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), PSXHIP_EDEVICE);
             const size_t fpad = c->call_out_off;
+            struct timespec ts[6];
+            auto tick = [&](int k) { if (c->call_trace) clock_gettime(CLOCK_MONOTONIC, &ts[k]); };
+            tick(0);
             memcpy(c->h_call, frames, fsz);
+            tick(1);
             HIP_TRY(psxhip_mdec_stage_in_launch(c->d_call, c->d_call_frame, fpad, c->stream), PSXHIP_EDEVICE);
+            tick(2);
             psxhip_mdec_batch_t bd;
             bd.d_frames = c->d_call_frame; bd.n_frames = 1; bd.reserved = 0; bd.d_frame_max_sizes = nullptr;
             bd.d_out = c->d_call + c->call_out_off; bd.d_results = (psxhip_mdec_result_t*)(c->d_call + c->call_res_off);
@@ -644,9 +701,33 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             if (dstride > (size_t)one) memset(c->h_call + c->call_out_off + one, 0, dstride - (size_t)one);   // (a row wider than the frame's own budget reads as zero there)
             int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream);
             if (rc) return rc;
+            tick(3);
             HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+            tick(4);
+            if (c->d_split_dbg) {          // diagnostics: where a split launch's time goes (one line per call on stderr)
+                static int shown = 0;
+                const int g = c->split_dbg_groups;
+                std::vector<unsigned long long> t((size_t)g * 8);
+                if (g > 0 && shown++ % 100 == 50 && hipMemcpy(t.data(), c->d_split_dbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    unsigned long long t0 = ~0ull;
+                    for (int i = 0; i < g; i++) if (t[(size_t)i * 8] < t0) t0 = t[(size_t)i * 8];
+                    fprintf(stderr, "split dbg (%d groups; ticks of 10 ns since the first group's start: min / max over groups)", g);
+                    static const char* nm[7] = {"start", "dct", "counted", "met", "emitted", "left", "last done"};
+                    for (int k = 0; k < 7; k++) {
+                        unsigned long long lo = ~0ull, hi = 0;
+                        for (int i = 0; i < g; i++) { const unsigned long long v = t[(size_t)i * 8 + k]; if (v < t0) continue; if (v - t0 < lo) lo = v - t0; if (v - t0 > hi) hi = v - t0; }
+                        fprintf(stderr, "  %s %llu/%llu", nm[k], lo == ~0ull ? 0 : lo, hi);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
             memcpy(out, c->h_call + c->call_out_off, (size_t)max_size);
             memcpy(results, c->h_call + c->call_res_off, sizeof(psxhip_mdec_result_t));
+            if (c->call_trace) {
+                tick(5);
+                for (int k = 0; k < 5; k++) c->call_ns[k] += (double)(ts[k + 1].tv_sec - ts[k].tv_sec) * 1e9 + (double)(ts[k + 1].tv_nsec - ts[k].tv_nsec);
+                c->call_ns[5] += 1.0;
+            }
             if (results[0].quant_scale >= 64) {
                 psxhip_set_error("frame %d does not fit %d bytes at any quant scale", 0, one);
                 return PSXHIP_ENOFIT;

@@ -43,6 +43,30 @@ typedef struct {
 	const uint32_t *d_order;        /* psxhip_mdec_pass_table() for this geometry, in device memory */
 } psxhip_mdec_launch_t;
 
+/* one frame across many workgroups (mdec_split.inc): launches of a few frames -- the drop-in's one frame per call most of all */
+typedef struct {
+	int seg_mbs, segs;                  /* macroblocks per workgroup (1, 2, 4, 8, 16), workgroups per frame */
+	int segbuf_words, img_words;
+	size_t ws_stride, ws_slots, ws_dcq, ws_img;   /* workspace bytes per frame and the offsets of its parts */
+	size_t lds_bytes;
+} psxhip_mdec_split_geo_t;
+typedef struct {
+	const uint8_t *d_frames;
+	uint8_t *d_out;                     /* written by plain stores only: may be page-locked host memory the device can see */
+	psxhip_mdec_result_t *d_results;
+	const int32_t *d_frame_max_sizes;
+	size_t frame_stride, out_stride;
+	int width, height, codec, n_frames, uniform_max_size, max_frame_size;
+	psxhip_mdec_split_geo_t geo;
+	void *d_ws;                         /* geo.ws_stride x n_frames bytes, all zero between launches (the kernel leaves it so) */
+	unsigned int *d_lost;               /* frames given up by the rendezvous watchdog */
+	unsigned long long *d_dbg;          /* diagnostics: [groups][8] phase stamps, or NULL */
+	void *stream;
+} psxhip_mdec_split_t;
+/* 1: the split kernel takes launches of n_frames frames of this geometry (g filled in), 0: it does not */
+int psxhip_mdec_split_geometry(int codec, int width, int height, int max_frame_size, int n_frames, int n_cu, psxhip_mdec_split_geo_t *g);
+hipError_t psxhip_mdec_split_launch(const psxhip_mdec_split_t *a);
+
 size_t psxhip_mdec_lds_bytes(int nmb, int out_words, int stg_words, int large);
 int psxhip_mdec_threads_per_group(int large);
 hipError_t psxhip_mdec_upload_tables(void);
