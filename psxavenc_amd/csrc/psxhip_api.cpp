@@ -114,6 +114,8 @@ struct psxhip_mdec_ctx {
     uint8_t* d_call_frame;
     size_t call_out_off, call_res_off;
     bool call_disabled;
+    bool call_bar;                    // d_call_frame is device memory the CPU writes straight into (large BAR): no stage-in launch
+    unsigned call_seq;                // the split kernel's last group stores it into the host block when row and result are there
     // launches of a few frames: one frame across many workgroups (mdec_split.inc)
     unsigned char* d_split_ws;        // [kLanes][split_max] per-frame workspaces, all zero between launches
     size_t split_ws_stride;
@@ -281,7 +283,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
         psxhip_mdec_split_geo_t g;
         if (c->split_max > 0 && psxhip_mdec_split_geometry(codec, width, height, max_frame_size, 1, c->n_cu, &g)) {
             c->split_ws_stride = g.ws_stride;
-            const size_t bytes = (size_t)kLanes * c->split_max * g.ws_stride;
+            const size_t bytes = (size_t)(kLanes + 1) * c->split_max * g.ws_stride;
             HIP_TRY(hipMalloc((void**)&c->d_split_ws, bytes), PSXHIP_ENOMEM);
             HIP_TRY(hipMemset(c->d_split_ws, 0, bytes), PSXHIP_EDEVICE);
             if (getenv("PSXHIP_MDEC_SPLIT_DBG")) HIP_TRY(hipMalloc((void**)&c->d_split_dbg, (size_t)c->split_max * c->n_cu * 8 * sizeof(unsigned long long)), PSXHIP_ENOMEM);
@@ -353,7 +355,8 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
 // One launch over the frames of `nb` batches (1 .. PSXHIP_MDEC_MAX_BATCHES, all vetted by the caller) on `stream`, with the
 // hand-out counters and the retry queue of launch lane `lane`.  Launches of one lane must be ordered (same stream, or events).
 static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batch_t* batches, int nb, size_t frame_stride,
-                            int uniform_max_size, size_t out_stride, hipStream_t stream) {
+                            int uniform_max_size, size_t out_stride, hipStream_t stream, unsigned* d_done_flag = nullptr,
+                            unsigned done_seq = 0, bool* flagged = nullptr) {
     int n_frames = 0;
     for (int i = 0; i < nb; i++) n_frames += batches[i].n_frames;
     // A launch of a few frames: every frame across many workgroups (the reference's own pattern, one frame per call, most of all:
@@ -367,7 +370,11 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
             sp.frame_stride = frame_stride; sp.out_stride = out_stride;
             sp.width = c->width; sp.height = c->height; sp.codec = c->codec; sp.n_frames = n_frames;
             sp.uniform_max_size = uniform_max_size; sp.max_frame_size = c->max_frame_size;
-            sp.d_ws = c->d_split_ws + (size_t)lane * c->split_max * c->split_ws_stride;
+            // (a one-frame call returns when its flag is up, while the kernel still tidies its workspace: it has one of its own, so that
+            //  a launch on a caller's stream right after cannot find lane 0's in use)
+            sp.d_ws = c->d_split_ws + (size_t)(d_done_flag ? kLanes : lane) * c->split_max * c->split_ws_stride;
+            sp.d_done_flag = d_done_flag; sp.done_seq = done_seq;
+            if (flagged) *flagged = d_done_flag != nullptr;
             sp.d_lost = c->d_ticket + 128 * lane + 3;
             sp.d_dbg = c->d_split_dbg;
             c->split_dbg_groups = sp.geo.segs * n_frames;
@@ -579,6 +586,20 @@ static void psxhip_mdec_free_staging(psxhip_mdec_ctx* c) {
 }
 
 namespace {
+// The frame of a one-frame call in device memory.  With a large BAR the CPU writes it there itself -- 115 KB in 2.3 us of
+// write-combined stores (tools/microbench/bar_probe.hip: 50 GB/s) -- where the copy kernel from the page-locked block took 6 us and
+// a launch of its own.  Fine-grained device memory: what the CPU wrote is what the next kernel reads.
+hipError_t call_frame_alloc(psxhip_mdec_ctx* c, size_t bytes) {
+    int large_bar = 0;
+    if (!getenv("PSXHIP_NO_BAR_WRITE") && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar &&
+        hipExtMallocWithFlags((void**)&c->d_call_frame, bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+        c->call_bar = true;
+        return hipSuccess;
+    }
+    (void)hipGetLastError();
+    c->call_bar = false;
+    return hipMalloc((void**)&c->d_call_frame, bytes);
+}
 // copy `bytes` with a few threads: one core moves ~10 GB/s, a pinned staging buffer can take several times that
 // is this host pointer page-locked memory the runtime knows about (hipHostMalloc / hipHostRegister)?
 bool host_pinned(const void* p) {
@@ -673,7 +694,7 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             void* dp = nullptr;
             if (getenv("PSXHIP_NO_PERCALL_PATH") ||
                 hipHostMalloc((void**)&c->h_call, fpad + opad + 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
-                hipHostGetDevicePointer(&dp, c->h_call, 0) != hipSuccess || hipMalloc((void**)&c->d_call_frame, fpad) != hipSuccess) {
+                hipHostGetDevicePointer(&dp, c->h_call, 0) != hipSuccess || call_frame_alloc(c, fpad) != hipSuccess) {
                 (void)hipGetLastError();
                 if (c->h_call) (void)hipHostFree(c->h_call);
                 c->h_call = nullptr;
@@ -690,30 +711,57 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             struct timespec ts[6];
             auto tick = [&](int k) { if (c->call_trace) clock_gettime(CLOCK_MONOTONIC, &ts[k]); };
             tick(0);
-            memcpy(c->h_call, frames, fsz);
-            tick(1);
-            HIP_TRY(psxhip_mdec_stage_in_launch(c->d_call, c->d_call_frame, fpad, c->stream), PSXHIP_EDEVICE);
+            if (c->call_bar) {
+                memcpy(c->d_call_frame, frames, fsz);          // write-combined stores through the BAR
+                __builtin_ia32_sfence();                       // ... all on their way before the doorbell rings
+                tick(1);
+            } else {
+                memcpy(c->h_call, frames, fsz);
+                tick(1);
+                HIP_TRY(psxhip_mdec_stage_in_launch(c->d_call, c->d_call_frame, fpad, c->stream), PSXHIP_EDEVICE);
+            }
             tick(2);
             psxhip_mdec_batch_t bd;
             bd.d_frames = c->d_call_frame; bd.n_frames = 1; bd.reserved = 0; bd.d_frame_max_sizes = nullptr;
             bd.d_out = c->d_call + c->call_out_off; bd.d_results = (psxhip_mdec_result_t*)(c->d_call + c->call_res_off);
             const int one = frame_max_sizes ? frame_max_sizes[0] : uniform_max_size;
             if (dstride > (size_t)one) memset(c->h_call + c->call_out_off + one, 0, dstride - (size_t)one);   // (a row wider than the frame's own budget reads as zero there)
-            int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream);
+            bool flagged = false;
+            volatile unsigned* h_flag = (volatile unsigned*)(c->h_call + c->call_res_off + 32);
+            const unsigned seq = ++c->call_seq ? c->call_seq : ++c->call_seq;
+            int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream, (unsigned*)(c->d_call + c->call_res_off + 32), seq, &flagged);
             if (rc) return rc;
             tick(3);
-            HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+            if (flagged) {
+                // the kernel's last group raises the flag when row and result are in this block: a look at our own memory instead of
+                // the stream's completion signal.  (A flag that does not come within 2 ms: the stream is waited for.)
+                struct timespec w0, w1;
+                clock_gettime(CLOCK_MONOTONIC, &w0);
+                for (unsigned spins = 0;; spins++) {
+                    if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) break;
+                    __builtin_ia32_pause();
+                    if ((spins & 1023u) == 1023u) {
+                        clock_gettime(CLOCK_MONOTONIC, &w1);
+                        if ((w1.tv_sec - w0.tv_sec) * 1000000000ll + (w1.tv_nsec - w0.tv_nsec) > 2000000ll) {
+                            HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+                            break;
+                        }
+                    }
+                }
+            } else {
+                HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+            }
             tick(4);
             if (c->d_split_dbg) {          // diagnostics: where a split launch's time goes (one line per call on stderr)
                 static int shown = 0;
                 const int g = c->split_dbg_groups;
                 std::vector<unsigned long long> t((size_t)g * 8);
-                if (g > 0 && shown++ % 100 == 50 && hipMemcpy(t.data(), c->d_split_dbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                if (g > 0 && shown++ % 100 == 50 && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(t.data(), c->d_split_dbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                     unsigned long long t0 = ~0ull;
                     for (int i = 0; i < g; i++) if (t[(size_t)i * 8] < t0) t0 = t[(size_t)i * 8];
                     fprintf(stderr, "split dbg (%d groups; ticks of 10 ns since the first group's start: min / max over groups)", g);
-                    static const char* nm[7] = {"start", "dct", "counted", "met", "emitted", "left", "last done"};
-                    for (int k = 0; k < 7; k++) {
+                    static const char* nm[8] = {"start", "dct", "counted", "met", "emitted", "left", "flag up", "last done"};
+                    for (int k = 0; k < 8; k++) {
                         unsigned long long lo = ~0ull, hi = 0;
                         for (int i = 0; i < g; i++) { const unsigned long long v = t[(size_t)i * 8 + k]; if (v < t0) continue; if (v - t0 < lo) lo = v - t0; if (v - t0 > hi) hi = v - t0; }
                         fprintf(stderr, "  %s %llu/%llu", nm[k], lo == ~0ull ? 0 : lo, hi);

@@ -61,6 +61,8 @@ typedef struct {
 	void *d_ws;                         /* geo.ws_stride x n_frames bytes, all zero between launches (the kernel leaves it so) */
 	unsigned int *d_lost;               /* frames given up by the rendezvous watchdog */
 	unsigned long long *d_dbg;          /* diagnostics: [groups][8] phase stamps, or NULL */
+	unsigned int *d_done_flag;          /* one-frame calls: a page-locked host word (device address) that receives done_seq when row and result are written, or NULL */
+	unsigned int done_seq;
 	void *stream;
 } psxhip_mdec_split_t;
 /* 1: the split kernel takes launches of n_frames frames of this geometry (g filled in), 0: it does not */
