@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <ctime>
 #include <mutex>
 #include <thread>
@@ -114,7 +115,10 @@ struct psxhip_mdec_ctx {
     uint8_t* d_call_frame;
     size_t call_out_off, call_res_off;
     bool call_disabled;
+    bool call_no_flush;               // PSXHIP_NO_HDP_FLUSH (measurements only: what the flush costs)
+    volatile uint32_t* hdp_flush;     // the device's HDP_MEM_FLUSH_CNTL register: CPU writes through the BAR are in the device's memory after a write and a read-back of it
     bool call_bar;                    // d_call_frame is device memory the CPU writes straight into (large BAR): no stage-in launch
+    int call_hint;                    // the previous one-frame call's answer: where the split kernel builds its streams before it knows the answer
     unsigned call_seq;                // the split kernel's last group stores it into the host block when row and result are there
     // launches of a few frames: one frame across many workgroups (mdec_split.inc)
     unsigned char* d_split_ws;        // [kLanes][split_max] per-frame workspaces, all zero between launches
@@ -275,6 +279,7 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     //  contexts alive two callers' streams shared one queue: their launches ran one after the other)
     c->n_cu = prop.multiProcessorCount;
     c->call_trace = getenv("PSXHIP_PERCALL_TRACE") != nullptr;
+    c->call_no_flush = getenv("PSXHIP_NO_HDP_FLUSH") != nullptr;
     {
         // one frame across many workgroups, for launches of at most split_max frames (PSXHIP_MDEC_SPLIT_MAX: experiments, 0 = off)
         c->split_max = 8;
@@ -374,6 +379,7 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
             //  a launch on a caller's stream right after cannot find lane 0's in use)
             sp.d_ws = c->d_split_ws + (size_t)(d_done_flag ? kLanes : lane) * c->split_max * c->split_ws_stride;
             sp.d_done_flag = d_done_flag; sp.done_seq = done_seq;
+            sp.hint = d_done_flag ? c->call_hint : 0;
             if (flagged) *flagged = d_done_flag != nullptr;
             sp.d_lost = c->d_ticket + 128 * lane + 3;
             sp.d_dbg = c->d_split_dbg;
@@ -589,9 +595,35 @@ namespace {
 // The frame of a one-frame call in device memory.  With a large BAR the CPU writes it there itself -- 115 KB in 2.3 us of
 // write-combined stores (tools/microbench/bar_probe.hip: 50 GB/s) -- where the copy kernel from the page-locked block took 6 us and
 // a launch of its own.  Fine-grained device memory: what the CPU wrote is what the next kernel reads.
+// The HDP flush register of a HIP device, from the HSA runtime HIP itself runs on (HSA_AMD_AGENT_INFO_HDP_FLUSH; the agent is matched
+// by PCI bus / device / function).  The symbols are looked up in the running process: no link-time dependency.  NULL: not available.
+volatile uint32_t* hdp_flush_register(int device) {
+    typedef int (*iterate_fn)(int (*)(uint64_t, void*), void*);
+    typedef int (*info_fn)(uint64_t, int, void*);
+    static iterate_fn iterate = (iterate_fn)dlsym(RTLD_DEFAULT, "hsa_iterate_agents");
+    static info_fn info = (info_fn)dlsym(RTLD_DEFAULT, "hsa_agent_get_info");
+    if (!iterate || !info) return nullptr;
+    int dom = 0, bus = 0, dev = 0, fn = 0;
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, sizeof id, device) != hipSuccess || sscanf(id, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) != 4) return nullptr;
+    struct Ctx { info_fn info; uint32_t bdf, dom; volatile uint32_t* reg; } ctx = {info, (uint32_t)(bus << 8 | dev << 3 | fn), (uint32_t)dom, nullptr};
+    iterate([](uint64_t agent, void* p) -> int {
+        Ctx* x = (Ctx*)p;
+        int type = 0;
+        uint32_t bdf = 0, dom = 0;
+        struct { uint32_t* mem; uint32_t* reg; } hdp = {nullptr, nullptr};
+        if (x->info(agent, 17 /* HSA_AGENT_INFO_DEVICE */, &type) != 0 || type != 1 /* GPU */) return 0;
+        if (x->info(agent, 0xA006 /* HSA_AMD_AGENT_INFO_BDFID */, &bdf) != 0 || bdf != x->bdf) return 0;
+        if (x->info(agent, 0xA00F /* HSA_AMD_AGENT_INFO_DOMAIN */, &dom) == 0 && dom != x->dom) return 0;
+        if (x->info(agent, 0xA00E /* HSA_AMD_AGENT_INFO_HDP_FLUSH */, &hdp) == 0) x->reg = hdp.mem;
+        return 0;
+    }, &ctx);
+    return ctx.reg;
+}
 hipError_t call_frame_alloc(psxhip_mdec_ctx* c, size_t bytes) {
     int large_bar = 0;
     if (!getenv("PSXHIP_NO_BAR_WRITE") && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar &&
+        (c->hdp_flush = hdp_flush_register(c->device)) != nullptr &&
         hipExtMallocWithFlags((void**)&c->d_call_frame, bytes, hipDeviceMallocFinegrained) == hipSuccess) {
         c->call_bar = true;
         return hipSuccess;
@@ -712,8 +744,14 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             auto tick = [&](int k) { if (c->call_trace) clock_gettime(CLOCK_MONOTONIC, &ts[k]); };
             tick(0);
             if (c->call_bar) {
-                memcpy(c->d_call_frame, frames, fsz);          // write-combined stores through the BAR
-                __builtin_ia32_sfence();                       // ... all on their way before the doorbell rings
+                // write-combined stores through the BAR, then the HDP flush that puts them in the device's memory: a register write,
+                // posted like the stores in front of it and like the doorbell behind it -- the device takes them in that order
+                memcpy(c->d_call_frame, frames, fsz);
+                __builtin_ia32_sfence();
+                if (!c->call_no_flush) {
+                    *c->hdp_flush = 1u;
+                    __builtin_ia32_sfence();
+                }
                 tick(1);
             } else {
                 memcpy(c->h_call, frames, fsz);
@@ -776,6 +814,7 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
                 for (int k = 0; k < 5; k++) c->call_ns[k] += (double)(ts[k + 1].tv_sec - ts[k].tv_sec) * 1e9 + (double)(ts[k + 1].tv_nsec - ts[k].tv_nsec);
                 c->call_ns[5] += 1.0;
             }
+            c->call_hint = results[0].quant_scale < 64 ? results[0].quant_scale : 0;
             if (results[0].quant_scale >= 64) {
                 psxhip_set_error("frame %d does not fit %d bytes at any quant scale", 0, one);
                 return PSXHIP_ENOFIT;

@@ -63,6 +63,7 @@ typedef struct {
 	unsigned long long *d_dbg;          /* diagnostics: [groups][8] phase stamps, or NULL */
 	unsigned int *d_done_flag;          /* one-frame calls: a page-locked host word (device address) that receives done_seq when row and result are written, or NULL */
 	unsigned int done_seq;
+	int hint;                           /* the answer of the context's previous one-frame call (0: none) */
 	void *stream;
 } psxhip_mdec_split_t;
 /* 1: the split kernel takes launches of n_frames frames of this geometry (g filled in), 0: it does not */
