@@ -567,15 +567,13 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     psxhip_adpcm_chain_t ch;
     ch.sample_offset = 0; ch.pitch = 1; ch.sample_limit = 0; ch.n_units = 0; ch.unit_stride = 1;
     int first = 0, count = 0, prev1 = 0, prev2 = 0, warm = 0;
-    long long rec0 = 0, st0 = 0;
     bool active = false;
     if (chunk_live) {
         const int c = job.chunk_chain[chunk];
         ch = job.chains[c];
         first = job.chunk_first[chunk];
         count = min(job.chunk_units, ch.n_units - first);
-        rec0 = job.unit_base[c];
-        st0 = job.state_base[c];
+        const long long st0 = job.state_base[c];          // (the chunk loop's copy is fetched behind the warm-up: see there)
         const int lead = job.lead_units[c];
         if (!VERIFY) {
             active = true;
@@ -601,15 +599,24 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
                 }
             }
         } else {
-            const psxhip_adpcm_state_t used = job.start_used[chunk];
-            const psxhip_adpcm_state_t truth = first > 0 ? job.unit_states[st0 + first - 1]
-                                                         : (job.start_known[c] ? job.chain_states[c] : used);
-            if (truth.prev1 != used.prev1 || truth.prev2 != used.prev2) {
+            // (scalars, not structs: a conditional between two loaded structs went through a stack slot -- 12 bytes of scratch per
+            //  lane that nothing ever read back)
+            const int used1 = job.start_used[chunk].prev1, used2 = job.start_used[chunk].prev2;
+            int truth1 = used1, truth2 = used2;
+            if (first > 0) {
+                truth1 = job.unit_states[st0 + first - 1].prev1;
+                truth2 = job.unit_states[st0 + first - 1].prev2;
+            } else if (job.start_known[c]) {
+                truth1 = job.chain_states[c].prev1;
+                truth2 = job.chain_states[c].prev2;
+            }
+            if (truth1 != used1 || truth2 != used2) {
                 active = true;
-                prev1 = truth.prev1;
-                prev2 = truth.prev2;
+                prev1 = truth1;
+                prev2 = truth2;
                 if (col == 0) {
-                    job.start_used[chunk] = truth;
+                    job.start_used[chunk].prev1 = truth1;
+                    job.start_used[chunk].prev2 = truth2;
                     *job.changed = 1;
                 }
             }
@@ -638,6 +645,14 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
     }
 
     // ---- the chunk itself
+    // (where its records and states go is fetched here, not in front of the warm-up: two 64-bit values a lane would carry through
+    //  the warm-up loop for nothing -- at 8 wavefronts per SIMD, 64 registers, they were its scratch spill)
+    long long rec0 = 0, st0 = 0;
+    if (chunk_live) {
+        const int c = job.chunk_chain[chunk];
+        rec0 = job.unit_base[c];
+        st0 = job.state_base[c];
+    }
     int n_run = active ? count : 0;
     int n_max = n_run;
     n_max = wave_max(n_max);

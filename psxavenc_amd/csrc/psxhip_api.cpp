@@ -281,8 +281,10 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     c->call_trace = getenv("PSXHIP_PERCALL_TRACE") != nullptr;
     c->call_no_flush = getenv("PSXHIP_NO_HDP_FLUSH") != nullptr;
     {
-        // one frame across many workgroups, for launches of at most split_max frames (PSXHIP_MDEC_SPLIT_MAX: experiments, 0 = off)
-        c->split_max = 8;
+        // one frame across many workgroups, for launches of at most split_max frames (PSXHIP_MDEC_SPLIT_MAX: experiments, 0 = off).
+        // 12: tools/gpu_r06_split_sweep.py -- 320x240: 14.7 us for one frame against the frame kernel's 40, 30 against 41 at 12 frames,
+        // 54 against 41 at 16; 640x480 v3: 34 against 171 for one, 152 against 172 at 12, 216 against 172 at 16
+        c->split_max = 12;
         if (const char* e = getenv("PSXHIP_MDEC_SPLIT_MAX")) c->split_max = atoi(e);
         if (c->split_max > 64) c->split_max = 64;
         psxhip_mdec_split_geo_t g;

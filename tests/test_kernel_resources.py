@@ -44,6 +44,97 @@ def test_frame_kernel_product_shapes_build_without_scratch():
         assert int(u["VGPRs"]) <= (80 if waves == 12 else 128), (name, u)
 
 
+def _listing(source):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                        "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "--cuda-device-only", "-S", source, "-o", "-"],
+                       cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def _functions(listing):
+    """{mangled name: its lines} of an AMDGPU assembly listing"""
+    out = {}
+    for chunk in re.split(r"\n(?=_Z\w+:)", listing):
+        name = chunk.split(":", 1)[0]
+        if name.startswith("_Z"):
+            out[name] = chunk.splitlines()
+    return out
+
+
+def _innermost_loop(lines, at):
+    """(first, last) line of the smallest backward-branch loop that contains line `at`"""
+    labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
+    loops = []
+    for i, ln in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    enclosing = [(a, b) for a, b in loops if a <= at <= b]
+    assert enclosing, at
+    return min(enclosing, key=lambda ab: ab[1] - ab[0])
+
+
+# scalar-register spills of the frame kernel: (SGPRs spilled, spill lane operations in the loops around the three matrix instructions --
+# pilot, pilot, pass loop) as they stand on mdec-k3.7.  A round-5 edit put spills INTO the macroblock loop (+1.5 % vector instructions)
+# and was found by A/B on hardware; with these ceilings it fails here, in the GPU-less container.
+SGPR_CEILINGS = {
+    (0, 16): (86, (31, 31, 8)), (0, 12): (86, (27, 27, 10)),
+    (1, 16): (133, (34, 34, 20)), (1, 12): (133, (34, 34, 17)),
+    (2, 16): (133, (34, 34, 20)), (2, 12): (133, (34, 34, 17)),
+}
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_frame_kernel_scalar_spills_stay_out_of_the_macroblock_loop():
+    use = _resource_usage("mdec_kernels.hip")
+    funcs = _functions(_listing("mdec_kernels.hip"))
+    seen = 0
+    for name, lines in funcs.items():
+        m = re.search(r"mdec_encode_frames_kernelILi(\d)ELi(\d+)ELi\d+ELb0EEE", name)
+        if not m:
+            continue
+        seen += 1
+        codec, waves = int(m.group(1)), int(m.group(2))
+        max_spill, max_ops = SGPR_CEILINGS[(codec, waves)]
+        assert int(use[name]["SGPRs Spill"]) <= max_spill, (name, use[name])
+        text = "\n".join(lines)
+        spill_regs = set(re.findall(r"v_writelane_b32\s+(v\d+)", text))          # the VGPRs scalar registers are spilled into
+        sites = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
+        assert len(sites) == 3, (name, sites)                                      # two pilot macroblocks, the pass loop
+        for site, ceiling in zip(sites, max_ops):
+            a, b = _innermost_loop(lines, site)
+            ops = 0
+            for ln in lines[a:b + 1]:
+                r = re.search(r"v_readlane_b32\s+s\d+,\s*(v\d+)", ln)
+                ops += 1 if (r and r.group(1) in spill_regs) or "v_writelane_b32" in ln else 0
+            assert ops <= ceiling, (name, "loop of lines %d..%d around the v_mfma at %d" % (a, b, site), ops, ceiling)
+    assert seen == 6
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_split_kernel_builds_without_scratch_at_two_groups_per_cu():
+    use = _resource_usage("mdec_kernels.hip")
+    shapes = {k: v for k, v in use.items() if "mdec_split_kernel" in k}
+    assert len(shapes) == 3, sorted(use)
+    for name, u in shapes.items():
+        # (scalar registers spilled into lanes of a vector register are no memory traffic; a latency-bound kernel does not feel them)
+        assert u["ScratchSize"] == "0" and u["VGPRs Spill"] == "0", (name, u)
+        assert int(u["VGPRs"]) <= 64, (name, u)           # 16 wavefronts per group, two groups per CU: 8 per SIMD
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_adpcm_kernels_build_without_scratch():
+    """every __global__ of adpcm_kernels.hip (adpcm_chunks_kernel<false, 12> carried 12 bytes of scratch per lane and two
+    spilled registers -- two 64-bit indices held across the warm-up loop; the verify instantiations 12 bytes nothing ever read)"""
+    use = _resource_usage("adpcm_kernels.hip")
+    assert sum("adpcm_chunks_kernel" in k for k in use) == 4 and any("adpcm_chains_kernel" in k for k in use), sorted(use)
+    for name, u in use.items():
+        assert u["ScratchSize"] == "0" and u["VGPRs Spill"] == "0" and u["SGPRs Spill"] == "0", (name, u)
+        if "adpcm_chunks_kernel" in name or "adpcm_chains_kernel" in name:
+            assert int(u["VGPRs"]) <= 64, (name, u)       # launch bounds (64, 8): eight wavefronts per SIMD is what the chunking counts on
+
+
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
 def test_scaler_kernels_build_without_scratch():
     use = _resource_usage("frontend_kernels.hip")
