@@ -36,28 +36,6 @@ __device__ __forceinline__ int predict(int k1, int k2, int p1, int p2) {
     return r >> 6;
 }
 
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
-    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
-// minimum over each 16-lane row, result in every lane of the row (row_ror:8,4,2,1)
-__device__ __forceinline__ uint64_t row_min_u64(uint64_t v) {
-    uint64_t o;
-    o = dpp64<0x128>(v); v = o < v ? o : v;
-    o = dpp64<0x124>(v); v = o < v ? o : v;
-    o = dpp64<0x122>(v); v = o < v ? o : v;
-    o = dpp64<0x121>(v); v = o < v ? o : v;
-    return v;
-}
-
-__device__ __forceinline__ uint64_t bperm64(int addr, uint64_t v) {
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)v), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(v >> 32));
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
 // maximum over the wavefront (a few times per kernel: loop bounds of rows with different lengths)
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -212,25 +190,31 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
         pk_lds[w * 64 + lane] = (lo | hi) & mask4;
     }
 
-    // ---- first strict minimum in (filter, shift) loop order == min of (sse, filter, shift)
-    const uint64_t key = valid ? (((uint64_t)sse << 8) | ((uint64_t)cd.f << 4) | (uint64_t)sh) : ~0ull;
-    uint64_t best;
+    // ---- first strict minimum in (filter, shift) loop order (adpcm.c:158-183).  A row's lanes ARE in that order (lane c owns filter
+    //      c / 3, shift m - 1 + c % 3), so the winner is the row's first lane whose error equals the row's minimum: a 32-bit minimum
+    //      and a ballot, where a 64-bit key (sse << 8 | filter << 4 | shift) took five 64-bit compare-and-select steps.  Lanes
+    //      without a candidate carry 2^32 - 1; a live unit always has a candidate that does not saturate (above).
+    const uint32_t mine = valid ? sse : 0xFFFFFFFFu;
+    uint32_t best = mine;
     if (ROW == 16) {
-        best = row_min_u64(key);
+        uint32_t o;
+        o = (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x128, 0xF, 0xF, false); best = o < best ? o : best;      // row_ror:8
+        o = (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x124, 0xF, 0xF, false); best = o < best ? o : best;      // row_ror:4
+        o = (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x122, 0xF, 0xF, false); best = o < best ? o : best;      // row_ror:2
+        o = (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x121, 0xF, 0xF, false); best = o < best ? o : best;      // row_ror:1
     } else {
         // 12-lane rows do not coincide with DPP rows: first the three lanes of a filter, then the four filters
-        best = key;
-        uint64_t o;
-        o = bperm64(cd.peer_a, best); best = o < best ? o : best;
-        o = bperm64(cd.peer_b, key); best = o < best ? o : best;
-        const uint64_t mine = best;
+        uint32_t o;
+        o = (uint32_t)__builtin_amdgcn_ds_bpermute(cd.peer_a, (int)mine); best = o < best ? o : best;
+        o = (uint32_t)__builtin_amdgcn_ds_bpermute(cd.peer_b, (int)mine); best = o < best ? o : best;
+        const uint32_t filt = best;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { o = bperm64(cd.peer_f[k], mine); best = o < best ? o : best; }
+        for (int k = 0; k < 3; k++) { o = (uint32_t)__builtin_amdgcn_ds_bpermute(cd.peer_f[k], (int)filt); best = o < best ? o : best; }
     }
-    const bool winner = valid && key == best;
-    const uint64_t wmask = __ballot(winner);
+    const uint64_t wmask = __ballot(valid && mine == best);
     const int wlane = ROW == 16 ? (int)__builtin_ctzll(((wmask >> (lane & 48)) & 0xFFFFull) | 0x10000ull) + (lane & 48)
                                 : (int)__builtin_ctzll(((wmask >> cd.row_base) & 0xFFFull) | 0x1000ull) + cd.row_base;
+    const bool winner = valid && lane == wlane;
     header = (uint32_t)((sh & 0x0F) | (cd.f << 4));
     const int np1 = __shfl(p1, wlane & 63, 64);
     const int np2 = __shfl(p2, wlane & 63, 64);

@@ -88,6 +88,7 @@ struct psxhip_mdec_ctx {
     bool lane_pending[2];           // lane_done[l] has been recorded and no caller stream has been ordered behind it yet
     int retry_patience;
     int trust_mode;                 // experiments (PSXHIP_MDEC_TRUST): 1 = foreign hints always trusted, 2 = never
+    bool spare_groups;              // PSXHIP_MDEC_SPARE (experiments, measured and not used)
     int max_run;                    // longest run of consecutive frames a frame ticket may be (4; PSXHIP_MDEC_RUN: experiments)
     unsigned long long* d_stats;    // diagnostics (PSXHIP_MDEC_STATS=1)
     unsigned prio_pattern;
@@ -253,6 +254,10 @@ extern "C" int psxhip_mdec_create(psxhip_mdec_ctx_t** out, int device, int codec
     HIP_TRY(psxhip_mdec_set_max_lds(codec, lds_cu), PSXHIP_EDEVICE);
     c->groups_max = prop.multiProcessorCount * (c->large ? 1 : 2);
     if (const char* e = getenv("PSXHIP_MDEC_GRID")) { const int g = atoi(e); if (g > 0 && g < c->groups_max) c->groups_max = g; }   // experiments
+    // the kernel's leave word packs four 16-bit sums, to each of which a group adds at most 63 (kTrustCap): the grid stays below
+    // 65535 / 63 groups so that none carries into its neighbour (1040; MI355X: 512)
+    if (c->groups_max > 1040) c->groups_max = 1040;
+    c->spare_groups = getenv("PSXHIP_MDEC_SPARE") != nullptr;      // experiments; read once
     c->prio_pattern = 0x2EE01u;      // younger group raised 6 steps in 8, older 1 (re-swept on mdec-k2.23: tools/gpu_prio_sweep.py)
     if (const char* e = getenv("PSXHIP_MDEC_PRIO")) c->prio_pattern = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("PSXHIP_MDEC_CKMARGIN")) c->ck_margin = atoi(e);      // experiments (tools/gpu_ckmargin_sweep.py)
@@ -429,7 +434,7 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
     //  500 runs on 512 slots -- and the kernel lets groups start without a ticket, to take handed-on frames only.  Measured: they
     //  never get any, because a group that finds not every group of its launch started may not wait and gives its place up at
     //  once; not used.)
-    if (queue && a.n_tickets < c->groups_max && n_frames > a.n_tickets && getenv("PSXHIP_MDEC_SPARE")) a.grid = c->groups_max;
+    if (queue && a.n_tickets < c->groups_max && n_frames > a.n_tickets && c->spare_groups) a.grid = c->groups_max;
     a.d_retry = queue ? c->d_retry + (size_t)lane * c->retry_cap : nullptr;
     a.retry_cap = queue ? c->retry_cap : 0;
     a.retry_patience = c->retry_patience;

@@ -31,7 +31,8 @@ const int kChunkedThreshold = []() {
 // trips are ~0.75 ms whatever the length, so below ~500 units serial wins; tools/gpu_r05_session_k.sh).  Many short chains keep the
 // serial kernel: it runs them all side by side.
 inline int chunked_threshold(int n_chains) {
-    if (getenv("PSXHIP_ADPCM_CHUNK_THRESHOLD")) return kChunkedThreshold;
+    static const bool forced = getenv("PSXHIP_ADPCM_CHUNK_THRESHOLD") != nullptr;      // experiments; read once
+    if (forced) return kChunkedThreshold;
     return n_chains <= 8 ? 512 : kChunkedThreshold;
 }
 
@@ -62,6 +63,7 @@ inline void pick_chunking(long long total_units, int rows, int device, int* chun
 }
 
 }  // namespace
+extern "C" int psxhip_adpcm_chunked_threshold(int n_chains) { return chunked_threshold(n_chains); }
 extern "C" void psxhip_adpcm_pick_chunking(long long total_units, int rows, int device, int* chunk_units, int* warmup_units) {
     pick_chunking(total_units, rows, device, chunk_units, warmup_units);
 }

@@ -9,7 +9,7 @@
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
 #define PSXHIP_MDEC_KERNEL_REV "mdec-k3.7"
 /* ... and with every change to the ADPCM kernels (round 4's kernels count as adpcm-k4.0) */
-#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.0"
+#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.1"
 
 #ifdef __cplusplus
 extern "C" {
@@ -128,6 +128,9 @@ typedef struct {
 } psxhip_str_video_job_t;
 int psxhip_str_video_sectors_launch(int device, const psxhip_str_video_job_t *a, void *stream);
 void psxhip_adpcm_pick_chunking(long long total_units, int rows, int device, int *chunk_units, int *warmup_units);
+/* units per chain from which a chain is cut along time (speculate-and-verify) instead of run serially; the host entry points and
+ * psxhip_str_encode_device ask the same function */
+int psxhip_adpcm_chunked_threshold(int n_chains);
 
 void psxhip_set_error(const char *fmt, ...);
 

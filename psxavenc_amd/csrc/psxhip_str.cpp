@@ -62,6 +62,7 @@ struct psxhip_str_ctx {
         int64_t pcm_samples = -1;
         const int16_t* d_pcm = nullptr;
         int64_t pcm_stream_stride = 0;
+        bool chunked = false;           // the XA tracks of the cached shape run as a speculate-and-verify session (else: serial chains)
         Plan plan;
         int n_vtab = 0, na = 0, nf = 0;
         void *d_vtab = nullptr, *d_budgets = nullptr, *d_adst = nullptr, *d_eof = nullptr, *d_bs = nullptr, *d_res = nullptr, *d_units = nullptr;
@@ -544,6 +545,13 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
         psxhip_set_error("psxhip_str_encode_device: NULL handle or bad stream count");
         return PSXHIP_EINVAL;
     }
+    if (plan_out) memset(plan_out, 0, sizeof *plan_out);
+    // (what the header promises the kernels: 4-byte aligned pointers and strides; a chain's sample limit is an int)
+    if (pcm_samples_per_channel < 0 || pcm_samples_per_channel > 0x7FFFFFFFll || ((uintptr_t)d_pcm & 3) || (n_streams > 1 && (pcm_stream_stride & 1)) ||
+        ((uintptr_t)d_frames & 3) || ((uintptr_t)d_out & 3) || (frames_stream_stride & 3) || (out_stream_stride & 3)) {
+        psxhip_set_error("psxhip_str_encode_device: pointers and strides must be 4-byte aligned, pcm_samples_per_channel within 0 .. 2^31 - 1");
+        return PSXHIP_EINVAL;
+    }
     std::lock_guard<std::mutex> call(c->mu);
     psxhip_str_ctx::Dev& d = c->dev;
     const int device = c->devices[0];
@@ -554,9 +562,10 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
                       memcmp(&d.settings, s, sizeof *s) == 0;
     if (!same) {
         Plan pl;
+        memset(&pl.pub, 0, sizeof pl.pub);
         const int rc = make_plan(s, n_frames, pcm_samples_per_channel, &pl);
-        if (plan_out) *plan_out = pl.pub;
         if (rc) return rc;
+        if (plan_out) *plan_out = pl.pub;
         // nothing of the old shape may still be running on the buffers that are about to go
         DEV_TRY(hipStreamSynchronize(S), PSXHIP_EDEVICE);
         if (d.astream) DEV_TRY(hipStreamSynchronize(d.astream), PSXHIP_EDEVICE);
@@ -697,8 +706,11 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
         DEV_TRY(hipEventRecord(d.ev_in, S), PSXHIP_EDEVICE);
         DEV_TRY(hipStreamWaitEvent(d.astream, d.ev_in, 0), PSXHIP_EDEVICE);
         const int n_chains = n_streams * ch;
-        const bool chunked = units_per_chain >= 4096;
-        if (d.d_pcm != d_pcm || d.pcm_stream_stride != pcm_stream_stride) {
+        const bool chunked = units_per_chain >= psxhip_adpcm_chunked_threshold(n_chains);      // (the rule of the host entry points)
+        // an error from here on leaves nothing of this call in flight on the caller's buffers
+        auto fail = [&](int code) { (void)hipStreamSynchronize(d.astream); (void)hipStreamSynchronize(S); return code; };
+        if (d.d_pcm != d_pcm || d.pcm_stream_stride != pcm_stream_stride || d.chunked != chunked) {
+            d.d_pcm = nullptr;          // (set again when the new session / tables stand: a failure below must not leave the old key on torn-down state)
             if (d.session) { psxhip_adpcm_session_destroy(d.session); d.session = nullptr; }
             std::vector<psxhip_adpcm_chain_t> chains((size_t)n_chains);
             std::vector<int32_t> base((size_t)n_chains);
@@ -717,18 +729,25 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
                 psxhip_adpcm_pick_chunking((long long)units_per_chain * n_chains, 5, device, &chunk_units, &warmup_units);
                 const int rc = psxhip_adpcm_session_create(&d.session, device, d_pcm, chains.data(), base.data(), nullptr, n_chains, 4, bits,
                                                            (uint8_t*)d.d_units, chunk_units, warmup_units, d.astream);
-                if (rc) return rc;
+                if (rc) return fail(rc);
             } else {
                 void** bufs[] = {&d.d_chains, &d.d_base, &d.d_states};
                 for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-                DEV_TRY(hipMalloc(&d.d_chains, chains.size() * sizeof(chains[0])), PSXHIP_ENOMEM);
-                DEV_TRY(hipMalloc(&d.d_base, base.size() * 4), PSXHIP_ENOMEM);
-                DEV_TRY(hipMalloc(&d.d_states, chains.size() * sizeof(psxhip_adpcm_state_t)), PSXHIP_ENOMEM);
-                DEV_TRY(hipMemcpy(d.d_chains, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice), PSXHIP_EDEVICE);
-                DEV_TRY(hipMemcpy(d.d_base, base.data(), base.size() * 4, hipMemcpyHostToDevice), PSXHIP_EDEVICE);
+                if (hipMalloc(&d.d_chains, chains.size() * sizeof(chains[0])) != hipSuccess || hipMalloc(&d.d_base, base.size() * 4) != hipSuccess ||
+                    hipMalloc(&d.d_states, chains.size() * sizeof(psxhip_adpcm_state_t)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    psxhip_set_error("psxhip_str_encode_device: out of device memory (chain tables)");
+                    return fail(PSXHIP_ENOMEM);
+                }
+                if (hipMemcpy(d.d_chains, chains.data(), chains.size() * sizeof(chains[0]), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d.d_base, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                    psxhip_set_error("psxhip_str_encode_device: chain tables: %s", hipGetErrorString(hipGetLastError()));
+                    return fail(PSXHIP_EDEVICE);
+                }
             }
             d.d_pcm = d_pcm;
             d.pcm_stream_stride = pcm_stream_stride;
+            d.chunked = chunked;
         }
         int rc;
         if (chunked) {
@@ -736,17 +755,17 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
             memset(zero.data(), 0, zero.size() * sizeof(zero[0]));
             psxhip_adpcm_session_reset(d.session);
             rc = psxhip_adpcm_session_run(d.session, zero.data(), nullptr, 0, nullptr, nullptr);
-            if (rc < 0) return rc;
+            if (rc < 0) return fail(rc);
         } else {
             DEV_TRY(hipMemsetAsync(d.d_states, 0, (size_t)n_chains * sizeof(psxhip_adpcm_state_t), d.astream), PSXHIP_EDEVICE);
             rc = psxhip_adpcm_encode_chains_device(device, d_pcm, (const psxhip_adpcm_chain_t*)d.d_chains, (const int32_t*)d.d_base, n_chains, 4,
                                                    bits, (psxhip_adpcm_state_t*)d.d_states, (uint8_t*)d.d_units, d.astream);
-            if (rc) return rc;
+            if (rc) return fail(rc);
         }
         rc = psxhip_xa_assemble_scatter(device, (const uint8_t*)d.d_units, na, s->format == FORMAT_STRCD ? 1 : 0, ch == 2, s->audio_frequency, bits,
                                         s->audio_xa_file, s->audio_xa_channel, 0, (const uint8_t*)d.d_eof, 0u, d_out, (const int32_t*)d.d_adst,
                                         n_streams, (size_t)units_per_stream * PSXHIP_ADPCM_RECORD_BYTES, out_stream_stride, d.astream);
-        if (rc) return rc;
+        if (rc) return fail(rc);
         DEV_TRY(hipEventRecord(d.ev_audio, d.astream), PSXHIP_EDEVICE);
         DEV_TRY(hipStreamWaitEvent(S, d.ev_audio, 0), PSXHIP_EDEVICE);
     }
