@@ -144,7 +144,7 @@ def compact_line(full, detail_path=None):
             c[k] = cfg[k]
     line["config"] = c
     roof = full.get("roofline") or {}
-    r = _scalars(roof, 140, skip=("note", "traffic_note", "kernel_ms_method", "traffic_key"))
+    r = _scalars(roof, 140, skip=("note", "traffic_note", "kernel_ms_method"))          # (traffic_key stays: tools/make_*_profile_summary.py key the counter index on it)
     if isinstance(roof.get("issue"), dict):
         r["valu_busy_frac"] = roof["issue"].get("valu_busy_frac")
     if isinstance(roof.get("step"), dict):
