@@ -146,3 +146,24 @@ def test_segment_sizes_all_agree():
         env = dict(os.environ, PSXHIP_MDEC_SPLIT_M=str(m))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (m, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_one_frame_calls_across_scene_cuts_follow_the_hint_and_stay_exact(codec):
+    """The reference's loop, one frame per call (filefmt.c:641-647), over cuts between quiet and noisy scenes: a call starts from the
+    answer of the call before it (eight scales in its first round when that was <= 6; streams built at the hinted scale while the sums
+    travel), so an answer that jumps from 2 to 20 and back takes the further rounds / the fallback emit -- same bytes either way."""
+    w, h, budget = 320, 240, 8192
+    amps = [2, 2, 30, 30, 3, 40, 2, 12, 20, 1, 50, 6, 18, 6]
+    frames = np.concatenate([O.synth_frames(w, h, 1, seed=90 + i, amp=a) for i, a in enumerate(amps)])
+    want, want_res, rc = O.mdec_encode(codec, w, h, frames, budget)
+    assert rc == 0
+    scales = want_res[:, 0].tolist()
+    assert min(scales) <= 3 and max(scales) > 16 and any(8 < s <= 16 for s in scales), scales
+    enc = _encoder(codec, w, h, budget)
+    for rep in range(2):
+        for k in range(len(amps)):
+            out, res = enc.encode_frames_host(frames[k:k + 1], budget)
+            assert np.array_equal(res[0], want_res[k]), (rep, k, res[0], want_res[k])
+            assert np.array_equal(out[0], want[k]), (rep, k)
+    enc.close()
