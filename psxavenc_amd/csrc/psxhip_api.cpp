@@ -19,6 +19,19 @@ namespace {
 
 thread_local char g_err[512] = "";
 std::mutex g_tables_mu;
+// Split launches (one frame across many workgroups: a frame's groups wait for each other, so all of them have to be resident) are
+// ordered one behind the other per device, whatever context, thread or stream they come from: a single launch always fits the
+// device (the geometry sees to that), but the groups of three or four launches dispatched side by side could fill every CU slot with
+// groups that each wait for siblings still in the queue -- nobody would finish until the watchdog lets go.  Asynchronous launches
+// chain on an event; a one-frame call holds the gate until its flag is up.  (Processes that share a GPU are not ordered against
+// each other: the watchdog is what is left there -- a released frame is flagged, counted, and the one-frame call takes it again
+// through the frame kernel.)
+struct SplitGate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    bool pending = false;
+};
+SplitGate g_split_gate[64];
 bool g_tables_ready[64] = {false};
 
 #define HIP_TRY(expr, code)                                                                   \
@@ -368,12 +381,12 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
 // hand-out counters and the retry queue of launch lane `lane`.  Launches of one lane must be ordered (same stream, or events).
 static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batch_t* batches, int nb, size_t frame_stride,
                             int uniform_max_size, size_t out_stride, hipStream_t stream, unsigned* d_done_flag = nullptr,
-                            unsigned done_seq = 0, bool* flagged = nullptr) {
+                            unsigned done_seq = 0, bool* flagged = nullptr, std::unique_lock<std::mutex>* gate_hold = nullptr, bool no_split = false) {
     int n_frames = 0;
     for (int i = 0; i < nb; i++) n_frames += batches[i].n_frames;
     // A launch of a few frames: every frame across many workgroups (the reference's own pattern, one frame per call, most of all:
     // one workgroup would encode it on ONE compute unit while 255 idle)
-    if (nb == 1 && n_frames <= c->split_max && !c->d_stats) {
+    if (nb == 1 && n_frames <= c->split_max && !c->d_stats && !no_split) {
         psxhip_mdec_split_t sp;
         memset(&sp, 0, sizeof sp);
         if (psxhip_mdec_split_geometry(c->codec, c->width, c->height, c->max_frame_size, n_frames, c->n_cu, &sp.geo)) {
@@ -392,7 +405,25 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
             sp.d_dbg = c->d_split_dbg;
             c->split_dbg_groups = sp.geo.segs * n_frames;
             sp.stream = stream;
+            static const bool no_gate = getenv("PSXHIP_NO_SPLIT_GATE") != nullptr;      // experiments only: what happens without the gate (tests/test_gpu_split_threads.py)
+            if (no_gate) {
+                HIP_TRY(psxhip_mdec_split_launch(&sp), PSXHIP_EDEVICE);
+                return PSXHIP_OK;
+            }
+            SplitGate& gate = g_split_gate[c->device & 63];
+            std::unique_lock<std::mutex> lk(gate.mu);
+            if (!gate.last) HIP_TRY(hipEventCreateWithFlags(&gate.last, hipEventDisableTiming), PSXHIP_EDEVICE);
+            if (gate.pending) {
+                if (hipEventQuery(gate.last) == hipSuccess) gate.pending = false;
+                else { (void)hipGetLastError(); HIP_TRY(hipStreamWaitEvent(stream, gate.last, 0), PSXHIP_EDEVICE); }
+            }
             HIP_TRY(psxhip_mdec_split_launch(&sp), PSXHIP_EDEVICE);
+            if (d_done_flag && gate_hold) {
+                *gate_hold = std::move(lk);          // the synchronous caller lets go when its flag is up
+            } else {
+                HIP_TRY(hipEventRecord(gate.last, stream), PSXHIP_EDEVICE);
+                gate.pending = true;
+            }
             return PSXHIP_OK;
         }
     }
@@ -774,7 +805,8 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             bool flagged = false;
             volatile unsigned* h_flag = (volatile unsigned*)(c->h_call + c->call_res_off + 32);
             const unsigned seq = ++c->call_seq ? c->call_seq : ++c->call_seq;
-            int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream, (unsigned*)(c->d_call + c->call_res_off + 32), seq, &flagged);
+            std::unique_lock<std::mutex> gate_hold;          // (split launches of a device go one behind the other: see SplitGate)
+            int rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream, (unsigned*)(c->d_call + c->call_res_off + 32), seq, &flagged, &gate_hold);
             if (rc) return rc;
             tick(3);
             if (flagged) {
@@ -796,6 +828,7 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
             } else {
                 HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
             }
+            if (gate_hold.owns_lock()) gate_hold.unlock();
             tick(4);
             if (c->d_split_dbg) {          // diagnostics: where a split launch's time goes (one line per call on stderr)
                 static int shown = 0;
@@ -814,8 +847,17 @@ extern "C" int psxhip_mdec_encode_frames_host_rows(psxhip_mdec_ctx_t* c, const u
                     fprintf(stderr, "\n");
                 }
             }
-            memcpy(out, c->h_call + c->call_out_off, (size_t)max_size);
             memcpy(results, c->h_call + c->call_res_off, sizeof(psxhip_mdec_result_t));
+            if (flagged && results[0].quant_scale >= 64) {
+                // "nothing fits" from the split kernel is also what a frame says whose groups the watchdog released (another process
+                // holding the CUs for 0.2 s): the frame kernel has the last word -- the reference aborts here, nobody waits for this
+                HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+                rc = mdec_launch_lane(c, 0, &bd, 1, (fsz + 3) & ~(size_t)3, one, dstride, c->stream, nullptr, 0, nullptr, nullptr, true);
+                if (rc) return rc;
+                HIP_TRY(hipStreamSynchronize(c->stream), PSXHIP_EDEVICE);
+                memcpy(results, c->h_call + c->call_res_off, sizeof(psxhip_mdec_result_t));
+            }
+            memcpy(out, c->h_call + c->call_out_off, (size_t)max_size);
             if (c->call_trace) {
                 tick(5);
                 for (int k = 0; k < 5; k++) c->call_ns[k] += (double)(ts[k + 1].tv_sec - ts[k].tv_sec) * 1e9 + (double)(ts[k + 1].tv_nsec - ts[k].tv_nsec);
