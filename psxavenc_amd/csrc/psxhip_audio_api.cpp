@@ -45,6 +45,10 @@ inline int chunked_threshold(int n_chains) {
 // when the SIMDs that drew four do (config 5, 78 M units on one GPU: 1899 instead of 4096 units per chunk, 21.3 -> 24.4 M
 // sectors/s, still two verify passes; 1266: three passes, 950: four -- tools/gpu_xacd_chunk_sweep.sh).
 inline void pick_chunking(long long total_units, int rows, int device, int* chunk_units, int* warmup_units) {
+    // experiments (tools/gpu_r06_chunk_sweep.sh): PSXHIP_ADPCM_CHUNK / PSXHIP_ADPCM_WARM fix both, read once
+    static const int forced_chunk = [] { const char* e = getenv("PSXHIP_ADPCM_CHUNK"); return e ? atoi(e) : 0; }();
+    static const int forced_warm = [] { const char* e = getenv("PSXHIP_ADPCM_WARM"); return e ? atoi(e) : 128; }();
+    if (forced_chunk > 0) { *chunk_units = forced_chunk; *warmup_units = forced_warm; return; }
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu < 1) n_cu = 256;
     const long long per_round = 32ll * n_cu * rows;                        // chunks in flight when every slot holds a wavefront
