@@ -65,7 +65,12 @@ void psxhip_mdec_destroy(psxhip_mdec_ctx_t *ctx);
  * Launches on ONE context must be stream-ordered (same stream, or ordered by events): the context owns the
  * frame hand-out counters the kernel uses.  Use one context per concurrent stream (or two launch lanes, psxhip_mdec_set_lanes).
  * Per-frame budgets (device memory, not vetted by the host) outside [8, min(the context's max_frame_size,
- * out_stride)] make that frame's result quant_scale 64 and write nothing. */
+ * out_stride)] make that frame's result quant_scale 64 and write nothing.
+ * Launches of at most 12 frames (PSXHIP_MDEC_SPLIT_MAX) cut every frame across many workgroups (csrc/mdec_split.inc: the
+ * reference's call pattern is ONE frame per call, psxavenc/filefmt.c:641-647) -- same bytes, same results, same ordering rules.  Such
+ * launches of one process are ordered one behind the other per device; a frame whose workgroups could not all become resident
+ * within 0.2 s (another PROCESS holding the device's compute units) comes back with quant_scale 64 and is counted by
+ * psxhip_mdec_watchdog -- the host-buffer one-frame call takes such a frame again through the one-workgroup kernel by itself. */
 int psxhip_mdec_encode_frames_device(psxhip_mdec_ctx_t *ctx, const uint8_t *d_frames, size_t frame_stride,
                                      int n_frames, const int32_t *d_frame_max_sizes, int uniform_max_size,
                                      uint8_t *d_out, size_t out_stride, psxhip_mdec_result_t *d_results,
