@@ -1097,7 +1097,7 @@ def bench_xacd(args):
                                sec_cnt * sps, sec_cnt * units_per_sector_chain, unit_stride=2)
     base = np.array([c * sec_cnt * 144 + side for c in range(n_ch) for side in range(2)], np.int32)
     lead = np.full(2 * n_ch, lead_sec * units_per_sector_chain, np.int32)
-    d_units = torch.zeros((n_ch * sec_cnt * 144, 32), dtype=torch.uint8, device=dev)
+    d_units = torch.zeros((n_ch * sec_cnt * 144, adpcm.record_bytes(4)), dtype=torch.uint8, device=dev)
     init = np.zeros((2 * n_ch, 2), np.int32)
     torch.cuda.synchronize()
 
@@ -1157,7 +1157,7 @@ def bench_xacd(args):
         total_sectors = n_sectors * n_ch * args.steps
         value = total_sectors / elapsed
         alg = (sps * 4 + 2352) * sec_cnt * n_ch           # int16 stereo in + sector out, per step per rank
-        spec_bytes = (sps * 4 + 144 * (adpcm.RECORD_BYTES + 8)) * sec_cnt * n_ch      # the speculate kernel's own: PCM in, unit records + states out
+        spec_bytes = (sps * 4 + 144 * (adpcm.record_bytes(4) + 8)) * sec_cnt * n_ch      # the speculate kernel's own: PCM in, unit records + states out
         from psxavenc_amd import _lib as _plib
         try:
             _plib.lib().psxhip_adpcm_kernel_rev.restype = __import__("ctypes").c_char_p

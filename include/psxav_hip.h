@@ -194,10 +194,12 @@ typedef struct {
 	int32_t unit_stride;     /* record stride, normally 1 (2 for the halves of a stereo pair) */
 } psxhip_adpcm_chain_t;
 
-#define PSXHIP_ADPCM_RECORD_BYTES 32   /* byte 0: (shift & 15) | filter << 4; bytes 4..31: the 28 codes */
+#define PSXHIP_ADPCM_RECORD_BYTES 32   /* 8-bit codes: byte 0: (shift & 15) | filter << 4; bytes 4..31: the 28 codes.  Also the upper bound of a record's size */
+#define PSXHIP_ADPCM_RECORD_BYTES_4BIT 16   /* 4-bit codes (SPU, 4-bit XA): the layout of an SPU block (adpcm.c:367-372): header, 0, 14 bytes of two codes each (even sample low) */
+#define PSXHIP_ADPCM_RECORD_SIZE(bits) ((bits) == 4 ? PSXHIP_ADPCM_RECORD_BYTES_4BIT : PSXHIP_ADPCM_RECORD_BYTES)   /* bytes between the records of consecutive unit indices */
 
 /* Encode n_chains independent chains.  filter_count 5 (SPU) or 4 (XA); bits 4 or 8 (shift range
- * 12 / 8, adpcm.c:29-34).  Output: one 32-byte record per unit (see above) in d_units; d_states[c]
+ * 12 / 8, adpcm.c:29-34).  Output: one record per unit (PSXHIP_ADPCM_RECORD_SIZE(bits) bytes apart, see above) in d_units; d_states[c]
  * is read and updated.  Result per unit == libpsxav/adpcm.c:142-191 encode(). */
 int psxhip_adpcm_encode_chains_device(int device, const int16_t *d_samples, const psxhip_adpcm_chain_t *d_chains,
                                       const int32_t *d_unit_base, int n_chains, int filter_count, int bits,

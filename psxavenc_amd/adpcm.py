@@ -15,7 +15,13 @@ PSX_AUDIO_XA_FORMAT_XA, PSX_AUDIO_XA_FORMAT_XACD = 0, 1           # libpsxav.h:3
 PSX_AUDIO_XA_FREQ_SINGLE, PSX_AUDIO_XA_FREQ_DOUBLE = 18900, 37800  # libpsxav.h:34-37
 PSX_AUDIO_SPU_BLOCK_SIZE, PSX_AUDIO_SPU_SAMPLES_PER_BLOCK = 16, 28
 PSX_AUDIO_SPU_LOOP_END, PSX_AUDIO_SPU_LOOP_REPEAT, PSX_AUDIO_SPU_LOOP_START, PSX_AUDIO_SPU_LOOP_TRAP = 1, 3, 6, 5
-RECORD_BYTES = 32
+RECORD_BYTES = 32          # 8-bit codes (and the upper bound)
+
+
+def record_bytes(bits):
+    """bytes between the records of consecutive unit indices (PSXHIP_ADPCM_RECORD_SIZE): 4-bit material keeps 16-byte records in
+    the layout of an SPU block"""
+    return 16 if bits == 4 else RECORD_BYTES
 
 
 def _bind():
@@ -195,7 +201,7 @@ def encode_chains_device(d_samples, chains, unit_base, filter_count, bits, d_sta
 
     chunk_units == 0: one serial pass per chain (psxhip_adpcm_encode_chains_device, asynchronous).
     chunk_units  > 0: speculate-and-verify along time (psxhip_adpcm_encode_chains_chunked, synchronous).
-    Returns (d_units (total_units, 32) uint8, d_states (n_chains, 2) int32, verify_passes)."""
+    Returns (d_units (total_units, record_bytes(bits)) uint8, d_states (n_chains, 2) int32, verify_passes)."""
     import torch
     L = _bind()
     L.psxhip_adpcm_encode_chains_chunked.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -208,7 +214,7 @@ def encode_chains_device(d_samples, chains, unit_base, filter_count, bits, d_sta
     if d_states is None:
         d_states = torch.zeros((n, 2), dtype=torch.int32, device=dev)
     if d_units is None:
-        d_units = torch.zeros((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=dev)
+        d_units = torch.zeros((max(total, 1), record_bytes(bits)), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     if chunk_units > 0:
         rc = L.psxhip_adpcm_encode_chains_chunked(dev.index or 0, d_samples.data_ptr(), chains.ctypes.data, unit_base.ctypes.data,
@@ -294,7 +300,7 @@ class AdpcmSession:
         self.n_chains = self.chains.size
         dev = d_samples.device
         total = int((self.unit_base + (self.chains["n_units"] - 1) * self.chains["unit_stride"]).max()) + 1 if self.n_chains else 0
-        self.d_units = d_units if d_units is not None else torch.zeros((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=dev)
+        self.d_units = d_units if d_units is not None else torch.zeros((max(total, 1), record_bytes(bits)), dtype=torch.uint8, device=dev)
         self.d_samples = d_samples          # keep alive
         lead = None if lead_units is None else np.ascontiguousarray(lead_units, dtype=np.int32)
         self._h = C.c_void_p()

@@ -25,7 +25,12 @@
 
 namespace {
 
-constexpr int kRecordBytes = 32;   // [0] header, [4..31] 28 codes
+// A sound unit's record.  8-bit codes (XA): 32 bytes -- [0] header, [4..31] the 28 codes.  4-bit codes (SPU, XA): 16 bytes IN THE
+// LAYOUT OF AN SPU BLOCK (adpcm.c:367-372) -- [0] header, [1] 0, [2..15] the codes two to a byte (even sample low) -- half the bytes the
+// encoders write and the sector assembly reads back (round 6; the records of a 4-bit job were 2.5 GB of config 5's 3.7 GB of writes).
+constexpr int kRecordBytes = 32;
+constexpr int kRecordBytes4 = 16;
+__device__ __forceinline__ int record_bytes(int range) { return range == 12 ? kRecordBytes4 : kRecordBytes; }
 
 // (k1 p1 + k2 p2 + 32) >> 6  (adpcm.c:63,106).  Taps and history fit 24 bits (|k| <= 122, history is int16): full-rate
 // 24-bit multiply-adds, and the p2 product is off the recursion's critical path.
@@ -262,7 +267,27 @@ __device__ __forceinline__ void stage_unit(int* xs, const UnitFetch& f, int lane
     wave_sync();
 }
 
-__device__ __forceinline__ void store_record(uint8_t* units, long long index, uint32_t header, const uint32_t* pk_lds, int lane) {
+// [header][flags = 0][14 x (even | odd << 4)]  (adpcm.c:367-372).  A word of pk_lds holds four codes, one per byte, each below 16:
+// c | c >> 4 pairs them up in bytes 0 and 2, one byte permute takes those of two words.
+__device__ __forceinline__ void store_spu_block(uint8_t* out, long long index, uint32_t header, const uint32_t* pk_lds, int lane) {
+    uint32_t t[7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        const uint32_t c = pk_lds[w * 64 + lane];
+        t[w] = c | (c >> 4);
+    }
+    uint4 v;
+    v.x = __builtin_amdgcn_perm(t[0], header & 0xFFu, 0x06040C00u);      // header, 0, codes 0..3
+    v.y = __builtin_amdgcn_perm(t[2], t[1], 0x06040200u);
+    v.z = __builtin_amdgcn_perm(t[4], t[3], 0x06040200u);
+    v.w = __builtin_amdgcn_perm(t[6], t[5], 0x06040200u);
+    *(uint4*)(out + index * 16) = v;
+}
+__device__ __forceinline__ void store_record(uint8_t* units, long long index, uint32_t header, const uint32_t* pk_lds, int lane, int range) {
+    if (range == 12) {          // (wave-uniform)
+        store_spu_block(units, index, header, pk_lds, lane);
+        return;
+    }
     uint32_t* rec = (uint32_t*)(units + index * kRecordBytes);
     rec[0] = header;
 #pragma unroll
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chains_kernel(const ChainJob job)
         if (u + 1 < n_max) nxt = fetch_unit<16>(src, ch, u + 1, chain_live && u + 1 < ch.n_units, lane);   // prefetch
         uint32_t header;
         if (encode_unit<16>(cd, xs, unit_live, lane, prev1, prev2, header, pk_lds))
-            store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
+            store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane, job.range);
     }
     if (chain_live && (lane & 15) == 0) {
         job.states[chain].prev1 = prev1;
@@ -333,22 +358,6 @@ struct CallJob {
     uint8_t* units;                         // 32-byte records (XA), or NULL
     uint8_t* spu_out;                       // packed 16-byte SPU blocks, or NULL
 };
-
-__device__ __forceinline__ void store_spu_block(uint8_t* out, long long index, uint32_t header, const uint32_t* pk_lds, int lane) {
-    // [header][flags = 0][14 x (even | odd << 4)]  (adpcm.c:367-372); a word of pk_lds holds four codes, one per byte
-    uint32_t nib[7];
-#pragma unroll
-    for (int w = 0; w < 7; w++) {
-        const uint32_t c = pk_lds[w * 64 + lane];
-        nib[w] = (c & 0x0Fu) | (((c >> 8) & 0x0Fu) << 4) | (((c >> 16) & 0x0Fu) << 8) | (((c >> 24) & 0x0Fu) << 12);     // two packed bytes
-    }
-    uint4 v;
-    v.x = (header & 0xFFu) | (nib[0] << 16);
-    v.y = nib[1] | (nib[2] << 16);
-    v.z = nib[3] | (nib[4] << 16);
-    v.w = nib[5] | (nib[6] << 16);
-    *(uint4*)(out + index * 16) = v;
-}
 
 __global__ __launch_bounds__(64) void adpcm_call_kernel(const CallJob job) {
     const int lane = (int)(threadIdx.x & 63);
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(64) void adpcm_call_kernel(const CallJob job) {
     int* xs = xs_all[row];
     auto put = [&](int u, uint32_t header) {
         if (job.spu_out) store_spu_block(job.spu_out, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
-        else store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
+        else store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane, job.range);
     };
     // ---- phase 1: every row its segment (the speculating rows start kCallWarm units early, from a zero state)
     const int u0 = seg == 0 ? 0 : seg_s - kCallWarm;               // (L0 >= kCallWarm: never negative)
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
         // THIS unit may still differ (different start, same end), so it is written, then the chunk stops.
         if (VERIFY && live && old.prev1 == prev1 && old.prev2 == prev2) running = false;
         if (more) stage_unit<ROW>(xs_b, nxt, lane);
-        if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane);
+        if (winner) store_record(job.units, rec0 + (long long)u * ch.unit_stride, header, pk_lds, lane, job.range);
         if (live && col == 0) {
             psxhip_adpcm_state_t s1;
             s1.prev1 = prev1;
@@ -686,24 +695,10 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
 
 // ---- SPU block packing (adpcm.c:367-372): [header][flags = 0][14 x (even | odd << 4)]
 __global__ void spu_pack_kernel(const uint8_t* units, int n_blocks, uint8_t* out) {
+    // (a 4-bit record IS the block: a copy, kept as the place where the two layouts would part again)
     const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (b >= n_blocks) return;
-    const uint32_t* rec = (const uint32_t*)(units + (size_t)b * kRecordBytes);
-    uint32_t o[4];
-    uint8_t bytes[16];
-    bytes[0] = (uint8_t)rec[0];
-    bytes[1] = 0;
-#pragma unroll
-    for (int w = 0; w < 7; w++) {
-        const uint32_t c = rec[1 + w];
-        bytes[2 + 2 * w] = (uint8_t)((c & 0x0F) | (((c >> 8) & 0x0F) << 4));
-        bytes[3 + 2 * w] = (uint8_t)(((c >> 16) & 0x0F) | (((c >> 24) & 0x0F) << 4));
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | ((uint32_t)bytes[4 * k + 3] << 24);
-    uint4 v = {o[0], o[1], o[2], o[3]};
-    *(uint4*)(out + (size_t)b * 16) = v;
+    *(uint4*)(out + (size_t)b * 16) = *(const uint4*)(units + (size_t)b * kRecordBytes4);
 }
 
 // ---- XA sector assembly.  One 256-thread workgroup per sector; the sector is built in LDS as a full
@@ -800,36 +795,49 @@ __global__ __launch_bounds__(256) void xa_assemble_kernel(const XaJob job) {
     }
 
     // sound groups: 18 x 128 bytes at sector offset 0x18 (adpcm.c:193-233,311-322)
-    const uint8_t* rec0 = job.units + (size_t)blockIdx.y * job.units_stream_stride + (size_t)s * 18 * upg * kRecordBytes;
+    const uint8_t* rec0 = job.units + (size_t)blockIdx.y * job.units_stream_stride + (size_t)s * 18 * upg * (four ? kRecordBytes4 : kRecordBytes);
     if (four) {
         // 4-bit: sample w of the group's 8 units is the 4 bytes (u0 | u1 << 4, u2 | u3 << 4, u4 | u5 << 4, u6 | u7 << 4) at group
-        // byte 16 + 4 w.  A record holds its 28 codes as 7 dwords behind the header dword: thread (group, q) reads dword q of
-        // the 8 records, pairs the nibbles of all four samples at once and transposes the 4 x 4 bytes -- 16 contiguous
-        // output bytes from 8 dword loads (byte by byte it was 32 byte loads and 16 byte stores).
-        if (tid < 18 * 7) {
-            const int g = tid / 7, q = tid - g * 7;
-            const uint32_t* gr = (const uint32_t*)(rec0 + (size_t)g * 8 * kRecordBytes) + 1 + q;
-            uint32_t p[4];
+        // byte 16 + 4 w.  A record is an SPU block: [header][0][14 code bytes, two samples each].  Thread (group, q) reads dword q
+        // of the 8 records -- code bytes 4 q - 2 .. 4 q + 1, i.e. samples 8 q - 4 .. 8 q + 3 (q = 0: its upper half only) -- pairs
+        // the low nibbles (even samples) and the high nibbles (odd samples) of unit pairs for four code bytes at once, and
+        // transposes 4 x 4 bytes twice: 32 contiguous sector bytes from 8 dword loads.
+        if (tid < 18 * 4) {
+            const int g = tid >> 2, q = tid & 3;
+            const uint32_t* gr = (const uint32_t*)(rec0 + (size_t)g * 8 * kRecordBytes4) + q;
+            uint32_t pe[4], po[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const uint32_t lo = gr[(2 * c) * (kRecordBytes / 4)], hi = gr[(2 * c + 1) * (kRecordBytes / 4)];
-                p[c] = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);          // byte j: column c of sample 4 q + j
+                const uint32_t lo = gr[(2 * c) * (kRecordBytes4 / 4)], hi = gr[(2 * c + 1) * (kRecordBytes4 / 4)];
+                pe[c] = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);          // byte j: column c of the EVEN sample of code byte j
+                po[c] = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);          // ... of the ODD sample
             }
-            // transpose: out[j] = (p0.j, p1.j, p2.j, p3.j)
-            const uint32_t a0 = __builtin_amdgcn_perm(p[1], p[0], 0x05010400u), a1 = __builtin_amdgcn_perm(p[1], p[0], 0x07030602u);   // (p0.0 p1.0 p0.1 p1.1), (p0.2 p1.2 p0.3 p1.3)
-            const uint32_t b0 = __builtin_amdgcn_perm(p[3], p[2], 0x05010400u), b1 = __builtin_amdgcn_perm(p[3], p[2], 0x07030602u);
-            uint4 o;
-            o.x = __builtin_amdgcn_perm(b0, a0, 0x05040100u);      // (p0.0 p1.0 p2.0 p3.0)
-            o.y = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
-            o.z = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
-            o.w = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-            uint32_t* dst = sec32 + (0x18 + g * 128 + 16 + 16 * q) / 4;        // (0x18 + 128 g + 16 + 16 q: a multiple of 8)
-            dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w;
+            // transpose: e[j] = (pe0.j, pe1.j, pe2.j, pe3.j) = the four bytes of sample 2 * (code byte j), o[j] likewise of the sample after it
+            uint32_t e[4], o[4];
+            {
+                const uint32_t a0 = __builtin_amdgcn_perm(pe[1], pe[0], 0x05010400u), a1 = __builtin_amdgcn_perm(pe[1], pe[0], 0x07030602u);
+                const uint32_t b0 = __builtin_amdgcn_perm(pe[3], pe[2], 0x05010400u), b1 = __builtin_amdgcn_perm(pe[3], pe[2], 0x07030602u);
+                e[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u); e[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+                e[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u); e[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+            }
+            {
+                const uint32_t a0 = __builtin_amdgcn_perm(po[1], po[0], 0x05010400u), a1 = __builtin_amdgcn_perm(po[1], po[0], 0x07030602u);
+                const uint32_t b0 = __builtin_amdgcn_perm(po[3], po[2], 0x05010400u), b1 = __builtin_amdgcn_perm(po[3], po[2], 0x07030602u);
+                o[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u); o[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u); o[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+            }
+            // dword q holds record bytes 4 q .. 4 q + 3 = code bytes 4 q - 2 + j: samples 2 (4 q - 2 + j) and the one after
+            uint32_t* grp = sec32 + (0x18 + g * 128 + 16) / 4;        // the group's 28 sample dwords
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int cb = 4 * q - 2 + j;                         // code byte (q = 0: j = 0, 1 are header and flags)
+                if (cb >= 0) { grp[2 * cb] = e[j]; grp[2 * cb + 1] = o[j]; }
+            }
         } else if (tid >= 128 && tid < 128 + 18 * 2) {
             // header bytes: units {0,1,2,3} at 0..3 and 4..7, units {4..7} at 8..11 and 12..15
             const int g = (tid - 128) >> 1, half = (tid - 128) & 1;
-            const uint8_t* gr = rec0 + (size_t)g * 8 * kRecordBytes + (size_t)half * 4 * kRecordBytes;
-            const uint32_t h = (uint32_t)gr[0] | (uint32_t)gr[kRecordBytes] << 8 | (uint32_t)gr[2 * kRecordBytes] << 16 | (uint32_t)gr[3 * kRecordBytes] << 24;
+            const uint8_t* gr = rec0 + (size_t)g * 8 * kRecordBytes4 + (size_t)half * 4 * kRecordBytes4;
+            const uint32_t h = (uint32_t)gr[0] | (uint32_t)gr[kRecordBytes4] << 8 | (uint32_t)gr[2 * kRecordBytes4] << 16 | (uint32_t)gr[3 * kRecordBytes4] << 24;
             uint32_t* dst = sec32 + (0x18 + g * 128 + 8 * half) / 4;
             dst[0] = h; dst[1] = h;
         }

@@ -416,7 +416,7 @@ extern "C" int psxhip_xa_encode_streams_host_flags(int device, int format, int s
         if (rc) return rc;
     }
     for (int i = 0; i < n_streams; i++) {
-        rc = psxhip_xa_assemble_device(device, d_u.as<uint8_t>() + (size_t)i * units_per_stream * PSXHIP_ADPCM_RECORD_BYTES,
+        rc = psxhip_xa_assemble_device(device, d_u.as<uint8_t>() + (size_t)i * units_per_stream * PSXHIP_ADPCM_RECORD_SIZE(bits),
                                        sectors, format, stereo, frequency, bits, file_number, channel_number,
                                        lbas ? lbas[i] : 0, d_e.as<uint8_t>() + (size_t)i * sectors,
                                        d_o.as<uint8_t>() + (size_t)i * bytes, st);

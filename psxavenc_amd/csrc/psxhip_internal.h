@@ -9,7 +9,7 @@
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
 #define PSXHIP_MDEC_KERNEL_REV "mdec-k3.7"
 /* ... and with every change to the ADPCM kernels (round 4's kernels count as adpcm-k4.0) */
-#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.1"
+#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.2"
 
 #ifdef __cplusplus
 extern "C" {
@@ -100,7 +100,7 @@ typedef struct {
 	int32_t unit_base[4];
 	int n_chains, filter_count, bits;
 	psxhip_adpcm_state_t *states_out;    /* [n_chains] */
-	uint8_t *units;                      /* 32-byte records, or NULL when spu_out is given */
+	uint8_t *units;                      /* unit records (PSXHIP_ADPCM_RECORD_SIZE(bits) apart), or NULL when spu_out is given */
 	uint8_t *spu_out;                    /* packed 16-byte SPU blocks */
 } psxhip_adpcm_call_t;
 hipError_t psxhip_adpcm_call_launch(const psxhip_adpcm_call_t *a, void *stream);

@@ -764,7 +764,7 @@ extern "C" int psxhip_str_encode_device(psxhip_str_ctx_t* c, const psxhip_str_se
         }
         rc = psxhip_xa_assemble_scatter(device, (const uint8_t*)d.d_units, na, s->format == FORMAT_STRCD ? 1 : 0, ch == 2, s->audio_frequency, bits,
                                         s->audio_xa_file, s->audio_xa_channel, 0, (const uint8_t*)d.d_eof, 0u, d_out, (const int32_t*)d.d_adst,
-                                        n_streams, (size_t)units_per_stream * PSXHIP_ADPCM_RECORD_BYTES, out_stream_stride, d.astream);
+                                        n_streams, (size_t)units_per_stream * PSXHIP_ADPCM_RECORD_SIZE(bits), out_stream_stride, d.astream);
         if (rc) return fail(rc);
         DEV_TRY(hipEventRecord(d.ev_audio, d.astream), PSXHIP_EDEVICE);
         DEV_TRY(hipStreamWaitEvent(S, d.ev_audio, 0), PSXHIP_EDEVICE);

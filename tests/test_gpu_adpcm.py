@@ -278,7 +278,7 @@ def test_time_sharded_sessions_simulated_ranks():
     n = n_units * 28
     pcm = np.stack([O.synth_pcm(77, c, 0, n, k) for c, k in enumerate((0, 4, 5))])
     d = torch.from_numpy(pcm).to("cuda:0").reshape(-1)
-    d_units = torch.zeros((n_chains * n_units, 32), dtype=torch.uint8, device="cuda:0")
+    d_units = torch.zeros((n_chains * n_units, adpcm.record_bytes(4)), dtype=torch.uint8, device="cuda:0")
     sessions = []
     for r in range(world):
         first, count = shard_range(n_units, r, world)

@@ -21,7 +21,7 @@ def run(n_chains, units_per_chain, filter_count, bits, kind=0, reps=5):
     d_chains = torch.from_numpy(chains.view(np.uint8)).to(dev)
     d_base = torch.arange(n_chains, dtype=torch.int32, device=dev) * units_per_chain
     d_states = torch.zeros((n_chains, 2), dtype=torch.int32, device=dev)
-    d_units = torch.zeros((n_chains * units_per_chain, 32), dtype=torch.uint8, device=dev)
+    d_units = torch.zeros((n_chains * units_per_chain, 16 if bits == 4 else 32), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     def go():
         d_states.zero_()

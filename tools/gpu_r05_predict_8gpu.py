@@ -53,7 +53,7 @@ def one(kind, seconds, world, n_ch=8, seed=1, chunk=None):
                                        sec_cnt * sps, sec_cnt * 72, unit_stride=2)
             base = np.array([c * sec_cnt * 144 + side for c in range(n_ch) for side in range(2)], np.int32)
             lead = np.full(2 * n_ch, lead_sec * 72, np.int32)
-            d_units = torch.zeros((n_ch * sec_cnt * 144, 32), dtype=torch.uint8, device="cuda")
+            d_units = torch.zeros((n_ch * sec_cnt * 144, 16), dtype=torch.uint8, device="cuda")
             cu, wu = adpcm.pick_chunking(int(chains["n_units"].sum()))
             if chunk and w > 1:
                 cu, wu = chunk      # (--chunk units,warmup: another chunking for the ranks' shares)
