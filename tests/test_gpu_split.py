@@ -167,3 +167,27 @@ def test_one_frame_calls_across_scene_cuts_follow_the_hint_and_stay_exact(codec)
             assert np.array_equal(res[0], want_res[k]), (rep, k, res[0], want_res[k])
             assert np.array_equal(out[0], want[k]), (rep, k)
     enc.close()
+
+
+@pytest.mark.parametrize("switch", ["PSXHIP_NO_BAR_WRITE", "PSXHIP_MDEC_SPLIT_MAX", "PSXHIP_NO_HDP_FLUSH", "PSXHIP_NO_PERCALL_PATH"])
+def test_one_frame_calls_on_the_fallback_paths(switch):
+    """the paths a system without a large BAR (frame through the page-locked block and a copy kernel), a context with the split kernel
+    off (every launch to the frame kernel), and the batched path (copies + chunks) take for one frame per call: the same bytes"""
+    from psxavenc_amd.mdec import MdecEncoder
+    w, h, budget = 320, 240, 8192
+    frames = O.synth_frames(w, h, 6, seed=55, amp=9)
+    want, want_res, rc = O.mdec_encode(1, w, h, frames, budget)
+    assert rc == 0
+    old = os.environ.get(switch)
+    os.environ[switch] = "0" if switch == "PSXHIP_MDEC_SPLIT_MAX" else "1"          # (read when the context / its call block is created)
+    try:
+        enc = MdecEncoder(1, w, h, max_frame_size=budget, device=0)
+        for k in range(6):
+            out, res = enc.encode_frames_host(frames[k:k + 1], budget)
+            assert np.array_equal(res[0], want_res[k]) and np.array_equal(out[0], want[k]), (switch, k)
+        enc.close()
+    finally:
+        if old is None:
+            os.environ.pop(switch, None)
+        else:
+            os.environ[switch] = old
