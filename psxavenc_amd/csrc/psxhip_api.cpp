@@ -29,6 +29,7 @@ std::mutex g_tables_mu;
 struct SplitGate {
     std::mutex mu;
     hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;      // the stream the last asynchronous split launch went to (launches on ONE stream are ordered as they are)
     bool pending = false;
 };
 SplitGate g_split_gate[64];
@@ -352,6 +353,16 @@ extern "C" void psxhip_mdec_destroy(psxhip_mdec_ctx_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    {
+        SplitGate& gate = g_split_gate[c->device & 63];          // (the gate must not keep a stream that is about to go)
+        std::lock_guard<std::mutex> lk(gate.mu);
+        if (gate.last_stream && (gate.last_stream == c->stream || gate.last_stream == c->stream2 || gate.last_stream == c->lane_stream[0] ||
+                                 gate.last_stream == c->lane_stream[1])) {
+            (void)hipStreamSynchronize(gate.last_stream);
+            gate.last_stream = nullptr;
+            gate.pending = false;
+        }
+    }
     for (int l = 0; l < kLanes; l++) {
         if (c->lane_stream[l]) { (void)hipStreamSynchronize(c->lane_stream[l]); (void)hipStreamDestroy(c->lane_stream[l]); }
         if (c->lane_in[l]) (void)hipEventDestroy(c->lane_in[l]);
@@ -413,17 +424,17 @@ static int mdec_launch_lane(psxhip_mdec_ctx* c, int lane, const psxhip_mdec_batc
             SplitGate& gate = g_split_gate[c->device & 63];
             std::unique_lock<std::mutex> lk(gate.mu);
             if (!gate.last) HIP_TRY(hipEventCreateWithFlags(&gate.last, hipEventDisableTiming), PSXHIP_EDEVICE);
-            if (gate.pending) {
-                if (hipEventQuery(gate.last) == hipSuccess) gate.pending = false;
-                else { (void)hipGetLastError(); HIP_TRY(hipStreamWaitEvent(stream, gate.last, 0), PSXHIP_EDEVICE); }
+            if (gate.pending && gate.last_stream != stream) {
+                // another stream than the last split launch's: an event recorded on THAT stream now stands behind everything it was
+                // given, the launch included.  (Launches that stay on one stream pay nothing.  A stream its owner has destroyed
+                // meanwhile is refused by the runtime: its work is done.)
+                if (hipEventRecord(gate.last, gate.last_stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(stream, gate.last, 0), PSXHIP_EDEVICE);
+                else (void)hipGetLastError();
             }
             HIP_TRY(psxhip_mdec_split_launch(&sp), PSXHIP_EDEVICE);
-            if (d_done_flag && gate_hold) {
-                *gate_hold = std::move(lk);          // the synchronous caller lets go when its flag is up
-            } else {
-                HIP_TRY(hipEventRecord(gate.last, stream), PSXHIP_EDEVICE);
-                gate.pending = true;
-            }
+            gate.last_stream = stream;
+            gate.pending = true;
+            if (d_done_flag && gate_hold) *gate_hold = std::move(lk);          // the synchronous caller lets go when its flag is up
             return PSXHIP_OK;
         }
     }

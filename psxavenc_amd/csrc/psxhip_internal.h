@@ -46,8 +46,8 @@ typedef struct {
 /* one frame across many workgroups (mdec_split.inc): launches of a few frames -- the drop-in's one frame per call most of all */
 typedef struct {
 	int seg_mbs, segs;                  /* macroblocks per workgroup (1, 2, 4, 8, 16), workgroups per frame */
-	int segbuf_words, img_words;
-	size_t ws_stride, ws_slots, ws_dcq, ws_img;   /* workspace bytes per frame and the offsets of its parts */
+	int img_words;
+	size_t ws_stride, ws_slots, ws_dcq, ws_img, ws_done;   /* workspace bytes per frame and the offsets of its parts */
 	size_t lds_bytes;
 } psxhip_mdec_split_geo_t;
 typedef struct {

@@ -64,3 +64,29 @@ def test_six_contexts_on_six_streams_twelve_frames_per_launch():
     assert lost == 0
     for e in encs:
         e.close()
+
+
+def test_a_stream_that_is_gone_does_not_trouble_the_next_launch():
+    """the gate remembers the stream of the last split launch (another stream's launch has to be ordered behind it); the owner may have
+    destroyed that stream meanwhile"""
+    import gc
+    import torch
+    from psxavenc_amd.mdec import MdecEncoder
+    w, h, budget = 160, 112, 4096
+    frames = O.synth_frames(w, h, 3, seed=9, amp=5)
+    want, want_res, rc = O.mdec_encode(0, w, h, frames, budget)
+    assert rc == 0
+    enc = MdecEncoder(0, w, h, max_frame_size=budget, device=0)
+    d = torch.from_numpy(frames).to("cuda:0")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        s = torch.cuda.Stream(device="cuda:0")
+        o1, r1 = enc.encode_frames_device(d, budget, stream=s)
+        s.synchronize()
+        del s
+        gc.collect()
+        o2, r2 = enc.encode_frames_device(d, budget)          # torch's current stream
+        torch.cuda.synchronize()
+        for o, r in ((o1, r1), (o2, r2)):
+            assert np.array_equal(r.cpu().numpy(), want_res) and np.array_equal(o.cpu().numpy()[:, :budget], want)
+    enc.close()
