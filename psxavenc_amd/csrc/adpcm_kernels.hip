@@ -1150,7 +1150,7 @@ extern "C" int psxhip_adpcm_session_create(psxhip_adpcm_session_t** out, int dev
     if (e == hipSuccess) e = s->d_cstates.alloc(sizeof(psxhip_adpcm_state_t) * nc);
     if (e == hipSuccess) e = s->d_final.alloc(sizeof(psxhip_adpcm_state_t) * nc);
     if (e == hipSuccess) e = s->d_known.alloc(nc);
-    if (e == hipSuccess) e = s->d_flags.alloc(16 * sizeof(int));
+    if (e == hipSuccess) e = s->d_flags.alloc(64 * sizeof(int));
     if (e == hipSuccess) e = s->d_cchain.alloc(sizeof(int32_t) * nk);
     if (e == hipSuccess) e = s->d_cfirst.alloc(sizeof(int32_t) * nk);
     if (e == hipSuccess) e = s->d_used.alloc(sizeof(psxhip_adpcm_state_t) * nk);
@@ -1250,7 +1250,7 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
         // back: pass i + 1 looks at pass i's word when it starts and returns at once if nothing changed, so the host reads the
         // words once per batch -- no synchronise + launch round trip (40-50 us) per pass.  The words travel back through a
         // page-locked buffer of the session (a run is synchronous).
-        constexpr int kBatchMax = 16;
+        constexpr int kBatchMax = 64;          // (the flags' room; batches grow 3, 6, 12, 16, 16 ... unless PSXHIP_ADPCM_VERIFY_BATCH says otherwise)
         int*& h_flags = s->h_flags;      // owned by the session (a buffer per calling thread leaked one per worker thread of the multi-device calls)
         if (!h_flags && hipHostMalloc((void**)&h_flags, kBatchMax * sizeof(int), hipHostMallocDefault) != hipSuccess) {
             h_flags = nullptr;
@@ -1275,7 +1275,10 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
             if (any_change) *any_change = 1;
         }
         // first batch: most material is done after "one pass that repairs + one that finds nothing"
-        int batch = 3;
+        // (experiments, PSXHIP_ADPCM_VERIFY_BATCH=n: every batch n passes -- with n = 48 a short stream's whole verify phase is ONE
+        //  batch, no host round trip in it: what the round trips cost, tools/gpu_r06_verify_batch.sh)
+        static const int forced_batch = [] { const char* e = getenv("PSXHIP_ADPCM_VERIFY_BATCH"); const int v = e ? atoi(e) : 0; return v > 64 ? 64 : v; }();
+        int batch = forced_batch > 0 ? forced_batch : 3;
         for (bool done = false; !done;) {
             if (max_passes > 0 && passes + batch > max_passes) batch = max_passes - passes;
             if (batch < 1) {
@@ -1297,7 +1300,7 @@ extern "C" int psxhip_adpcm_session_run(psxhip_adpcm_session_t* s, const psxhip_
                 if (h_flags[i]) { if (any_change) *any_change = 1; }
                 else done = true;              // it changed nothing: the fixpoint; the passes behind it returned at once
             }
-            batch = batch * 2 < kBatchMax ? batch * 2 : kBatchMax;
+            batch = forced_batch > 0 ? forced_batch : (batch * 2 < 16 ? batch * 2 : 16);
         }
         if (timed) {
             TRY(hipEventRecord(s->ev[2], st));
