@@ -114,7 +114,7 @@ __device__ __forceinline__ Candidate make_candidate(int lane, int filter_count, 
 // the rows read different addresses, and at a stride of 32 ints rows 0, 2, 4 met in one LDS bank (PMC: five conflict cycles per LDS
 // instruction of the speculating kernel); 33 puts the wavefront's rows into different banks for every sample index.
 constexpr int kXsStride = 33;
-template <int ROW>
+template <int ROW, bool FLAT = false>
 __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, bool unit_live, int lane, int& prev1,
                                             int& prev2, uint32_t& header, uint32_t* pk_lds /* [7][64] per wavefront */) {
     // ---- find_min_shift for this lane's filter (adpcm.c:39-79): history continues with RAW samples, so only the first two
@@ -166,8 +166,10 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
     const int qmin_v = cd.qmin;
     const uint32_t up = (uint32_t)(cd.range - sh);
     const uint32_t mask4 = (uint32_t)cd.qmask * 0x01010101u;
-#pragma unroll 1
-    for (int w = 0; w < 7; w++) {
+    // (FLAT: the verify passes' instantiation -- a handful of wavefronts on an empty GPU, each the serial chase of a wrong start state:
+    //  the trial loop unrolled, its 28 broadcast reads and stores off the recursion's chain; the speculating kernel keeps it rolled: there
+    //  eight wavefronts share a SIMD and 64 registers each is what lets them)
+    auto trial_word = [&](int w) {
         int qs[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -193,6 +195,13 @@ __device__ __forceinline__ bool encode_unit(const Candidate& cd, const int* xs, 
         const uint32_t lo = __builtin_amdgcn_perm((uint32_t)qs[1], (uint32_t)qs[0], 0x0C0C0400u);
         const uint32_t hi = __builtin_amdgcn_perm((uint32_t)qs[3], (uint32_t)qs[2], 0x04000C0Cu);
         pk_lds[w * 64 + lane] = (lo | hi) & mask4;
+    };
+    if (FLAT) {
+#pragma unroll
+        for (int w = 0; w < 7; w++) trial_word(w);
+    } else {
+#pragma unroll 1
+        for (int w = 0; w < 7; w++) trial_word(w);
     }
 
     // ---- first strict minimum in (filter, shift) loop order (adpcm.c:158-183).  A row's lanes ARE in that order (lane c owns filter
@@ -546,7 +555,7 @@ struct ChunkJob {
 };
 
 template <bool VERIFY, int ROW>
-__global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job) {
+__global__ __launch_bounds__(64, VERIFY ? 4 : 8) void adpcm_chunks_kernel(const ChunkJob job) {
     constexpr int kRows = 64 / ROW;            // chains per wavefront: 4 or 5
     // Verify passes are launched several at a time, back to back, without a host round trip in between (a synchronise + launch
     // per pass was 40-50 us, as much as re-encoding 40 sound units); the passes after the one that changed nothing fall through here
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(64, 8) void adpcm_chunks_kernel(const ChunkJob job)
             if (VERIFY && nlive) old_nxt = job.unit_states[st0 + u + 1];
         }
         uint32_t header;
-        const bool winner = encode_unit<ROW>(cd, xs_a, live, lane, prev1, prev2, header, pk_lds);
+        const bool winner = encode_unit<ROW, VERIFY>(cd, xs_a, live, lane, prev1, prev2, header, pk_lds);
         // (verify) coincided with the state stored for this unit: everything after it is already consistent.  The record of
         // THIS unit may still differ (different start, same end), so it is written, then the chunk stops.
         if (VERIFY && live && old.prev1 == prev1 && old.prev2 == prev2) running = false;

@@ -9,7 +9,7 @@
 /* bumped with every change to the MDEC kernel: bench.py keys the committed PMC summaries on it (profiles/pmc_index.json) */
 #define PSXHIP_MDEC_KERNEL_REV "mdec-k3.7"
 /* ... and with every change to the ADPCM kernels (round 4's kernels count as adpcm-k4.0) */
-#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.2"
+#define PSXHIP_ADPCM_KERNEL_REV "adpcm-k5.3"
 
 #ifdef __cplusplus
 extern "C" {
